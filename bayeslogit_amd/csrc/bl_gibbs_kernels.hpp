@@ -1,0 +1,85 @@
+// bl_gibbs_kernels.hpp -- launch interface between capi_gibbs.hip (host logic of
+// the Gibbs/EM/mlogit drivers) and kernels_gibbs.hip (the kernels).  Host-callable
+// C++ functions; every pointer is a device pointer.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blk {
+
+enum WeightMode : int {
+  W_DRAW = 0,   // omega_i ~ PG((int) n_i, psi_i)           Logit.hpp:283-289
+  W_EM = 1      // omega_i = n_i tanh(psi_i/2)/(2 psi_i)    Logit.hpp:509-519
+};
+
+// Geometry of the partial-sum workspace for X' Omega X (fixed per (N, P) so that
+// summation order -- and therefore every bit of PP -- is reproducible).
+struct SweepPlan {
+  int P = 0;
+  int fused = 0;          // 1: single-pass MFMA kernel (P in {16,32,48,64})
+  int nblocks = 0;        // workgroups of the sweep kernel
+  int nb = 0;             // fused: P/16
+  int ntile = 0;          // generic: number of 64x64 output tiles (upper triangle)
+  size_t partial_doubles = 0;   // workspace size
+};
+SweepPlan make_plan(int64_t N, int P, int num_cus);
+
+// One sweep over this rank's rows: psi_i = x_i.beta - off_i, omega_i by `mode`,
+// PPpart = sum_i omega_i x_i x_i' (full symmetric P x P, column-major).
+//   off     : per-row offset subtracted from psi (mlogit c_j), or nullptr
+//   w_store : where omega_i is written (N doubles), or nullptr.  The generic
+//             (non-fused) plan needs it and uses `w_scratch` when it is null.
+void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
+                  double* w_store, double* w_scratch, int64_t N, double* partial, double* PPpart, uint64_t seed,
+                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s);
+
+// out[j] = sum_i wgt_i x_ij, with wgt_i = n_i (y_i - 1/2) (kappa, Logit.hpp:174-183)
+// when w == nullptr, else wgt_i = w_i * c_i (c may be nullptr => 1).
+// ws: workspace of colsum_ws_doubles(N, P) doubles.
+size_t colsum_ws_doubles(int64_t N, int P);
+void launch_colsum(const double* tX, const double* y, const double* n, const double* w, const double* c, int64_t N,
+                   int P, double* ws, double* out, hipStream_t s);
+
+// psi = X beta (gemm(psi, tX, beta, 'T'), Logit.hpp:421,431) into out[N]
+void launch_xbeta(const double* tX, const double* beta, int64_t N, int P, double* out, hipStream_t s);
+
+// mlogit: c_i = log sum_{k != j} exp(XB[i,k]) over the J columns of XB (N x J, last
+// column zero), MultLogit.hpp:293-299.
+void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, hipStream_t s);
+
+// ---- P x P stage (one workgroup; redundant on every rank) ----
+struct BetaArgs {
+  int P;
+  const double* PPsum;     // sum over ranks of X' Omega X            (P*P)
+  const double* P0;        // prior precision                         (P*P)
+  const double* bP;        // P0 m0 + X' kappa  (or b1 for mlogit)    (P)
+  const double* beta_prev; // previous beta                           (P)
+  double* beta_out;        // new beta (may alias beta_prev)          (P)
+  double* work;            // beta_work_doubles(P) doubles of scratch
+  uint64_t seed;
+  uint32_t epoch;
+  int* status;             // BL_ERR_NOT_PD flag word (host-visible int, device memory)
+};
+size_t beta_work_doubles(int P);
+enum BetaMode : int {
+  B_MVN = 0,          // Logit::draw_beta(beta, w, r)            Logit.hpp:291-320
+  B_CONSTRAINED = 1,  // Logit::draw_beta(beta, w, beta_prev, r) Logit.hpp:322-400
+  B_FROM_LIK = 2,     // Normal::set_from_likelihood + draw      Normal.hpp:98-131
+  B_SOLVE = 3         // EM M-step: beta = PP^{-1} bP            Logit.hpp:537-540
+};
+void launch_beta(const BetaArgs& a, int mode, hipStream_t s);
+
+// dist = max_j |a_j - b_j| into *out (device double)
+void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s);
+// dst[j] = a[j] + (b ? b[j] : 0)
+void launch_vec_add(double* dst, const double* a, const double* b, int P, hipStream_t s);
+// dst = P0 * m0  (P x P times P)
+void launch_matvec(double* dst, const double* M, const double* v, int P, hipStream_t s);
+
+// ---- duplicate-row merge (Logit::compress, Logit.hpp:192-270; MultLogit::set_data
+// merge, MultLogit.hpp:137-208): rows with identical covariates are folded into
+// their first occurrence in index order; first-occurrence order is kept.
+// ty is U x N column-major (U = 1 for the binomial case).  Returns new N in *N_out.
+int combine_rows(double* ty, double* tX, double* n, int64_t N, int P, int U, int64_t* N_out, hipStream_t s);
+
+}  // namespace blk

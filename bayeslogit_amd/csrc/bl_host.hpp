@@ -1,0 +1,65 @@
+// bl_host.hpp -- host-side plumbing shared by the translation units of
+// libbayeslogit_hip.so: error/status reporting, process-global seed state, a
+// device scratch helper.  No CPU compute path lives here or anywhere in csrc/:
+// every entry point either runs HIP kernels or fails with a status.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/bayeslogit_hip.h"
+
+namespace blh {
+
+void set_error(const std::string& msg);
+bool ensure_device();                       // false => BL_ERR_NO_DEVICE recorded
+int* status_word(hipStream_t s);            // device int, zeroed per sync
+int  collect_status(hipStream_t s);         // sync + read + reset flags
+
+uint64_t global_seed();
+uint32_t next_epoch();                      // returns current, then increments
+int      global_constrain();
+
+#define BL_HIP_TRY(expr)                                                            \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      blh::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+      return BL_ERR_HIP;                                                            \
+    }                                                                               \
+  } while (0)
+
+// RAII device buffer for the host-pointer (.C) entry points
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count)
+  {
+    n = count;
+    return hipMalloc((void**)&p, sizeof(T) * (count ? count : 1));
+  }
+  hipError_t upload(const T* host, hipStream_t s = nullptr)
+  {
+    return hipMemcpyAsync(p, host, sizeof(T) * n, hipMemcpyHostToDevice, s);
+  }
+  hipError_t download(T* host, hipStream_t s = nullptr) const
+  {
+    return hipMemcpyAsync(host, p, sizeof(T) * n, hipMemcpyDeviceToHost, s);
+  }
+};
+
+inline int grid_for(int64_t n, int block, int max_blocks)
+{
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+}  // namespace blh

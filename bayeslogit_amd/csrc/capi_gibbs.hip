@@ -1,0 +1,520 @@
+// capi_gibbs.hip -- host logic of the Gibbs / EM / mlogit drivers behind the C ABI
+// (include/bayeslogit_hip.h).  Mirrors the sweep structure and slot semantics of
+// Code/C/Logit.hpp:402-481 and Code/C/MultLogit.hpp:261-372; all arithmetic runs in
+// the kernels of kernels_gibbs.hip.  There is no CPU compute path.
+#include <vector>
+
+#include "bl_gibbs_kernels.hpp"
+#include "bl_host.hpp"
+
+struct bl_gibbs {
+  int64_t N = 0;
+  int P = 0;
+  uint64_t idx0 = 0, seed = 0;
+  hipStream_t stream = nullptr;
+  blk::SweepPlan plan;
+  const double *tX = nullptr, *y = nullptr, *n = nullptr;   // not owned
+  double* pool = nullptr;   // one allocation, carved below
+  double *PP = nullptr, *bP = nullptr, *beta = nullptr, *beta_old = nullptr, *P0 = nullptr, *m0 = nullptr,
+         *b0 = nullptr, *partial = nullptr, *colws = nullptr, *wscr = nullptr, *work = nullptr, *dist = nullptr;
+};
+
+namespace {
+
+int num_cus()
+{
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+  return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+int valid(bl_gibbs* h)
+{
+  if (!h) {
+    blh::set_error("null gibbs handle");
+    return BL_ERR_ARG;
+  }
+  return BL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_gibbs_create(bl_gibbs** out, int64_t N_local, int P, uint64_t idx0, uint64_t seed, void* stream)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  if (!out || N_local < 0 || P < 1 || P > 1024) {
+    blh::set_error("bl_gibbs_create: bad arguments (need N >= 0, 1 <= P <= 1024)");
+    return BL_ERR_ARG;
+  }
+  bl_gibbs* h = new bl_gibbs;
+  h->N = N_local;
+  h->P = P;
+  h->idx0 = idx0;
+  h->seed = seed;
+  h->stream = (hipStream_t)stream;
+  h->plan = blk::make_plan(N_local, P, num_cus());
+  const size_t PPn = (size_t)P * P;
+  const size_t colws = blk::colsum_ws_doubles(N_local, P);
+  const size_t wscr = h->plan.fused ? 0 : (size_t)(N_local > 0 ? N_local : 1);
+  const size_t work = blk::beta_work_doubles(P);
+  const size_t total = 2 * PPn + 5 * (size_t)P + h->plan.partial_doubles + colws + wscr + work + 8;
+  hipError_t e = hipMalloc((void**)&h->pool, total * sizeof(double));
+  if (e == hipSuccess) e = hipMemsetAsync(h->pool, 0, total * sizeof(double), h->stream);
+  if (e != hipSuccess) {
+    blh::set_error(std::string("bl_gibbs_create: ") + hipGetErrorString(e));
+    delete h;
+    return BL_ERR_HIP;
+  }
+  double* p = h->pool;
+  h->PP = p; p += PPn;
+  h->P0 = p; p += PPn;
+  h->bP = p; p += P;
+  h->beta = p; p += P;
+  h->beta_old = p; p += P;
+  h->m0 = p; p += P;
+  h->b0 = p; p += P;
+  h->dist = p; p += 8;
+  h->partial = p; p += h->plan.partial_doubles;
+  h->colws = p; p += colws;
+  h->wscr = p; p += wscr;
+  h->work = p;
+  *out = h;
+  return BL_OK;
+}
+
+void bl_gibbs_destroy(bl_gibbs* h)
+{
+  if (!h) return;
+  if (h->pool) (void)hipFree(h->pool);
+  delete h;
+}
+
+int bl_gibbs_set_data(bl_gibbs* h, const double* tX, const double* y, const double* n)
+{
+  if (int rc = valid(h)) return rc;
+  if (h->N > 0 && (!tX || !n)) {
+    blh::set_error("bl_gibbs_set_data: null tX / n");
+    return BL_ERR_ARG;
+  }
+  if (((uintptr_t)tX & 15) != 0) {
+    blh::set_error("bl_gibbs_set_data: tX must be 16-byte aligned");
+    return BL_ERR_ARG;
+  }
+  h->tX = tX;
+  h->y = y;
+  h->n = n;
+  return BL_OK;
+}
+
+int bl_gibbs_set_prior(bl_gibbs* h, const double* m0, const double* P0)
+{
+  if (int rc = valid(h)) return rc;
+  const int P = h->P;
+  BL_HIP_TRY(hipMemcpyAsync(h->m0, m0, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+  BL_HIP_TRY(hipMemcpyAsync(h->P0, P0, sizeof(double) * P * P, hipMemcpyHostToDevice, h->stream));
+  BL_HIP_TRY(hipStreamSynchronize(h->stream));   // host buffers may be transient
+  blk::launch_matvec(h->b0, h->P0, h->m0, P, h->stream);   // b0 = P0 m0, Logit.hpp:189
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_gibbs_set_beta(bl_gibbs* h, const double* beta)
+{
+  if (int rc = valid(h)) return rc;
+  BL_HIP_TRY(hipMemcpyAsync(h->beta, beta, sizeof(double) * h->P, hipMemcpyHostToDevice, h->stream));
+  BL_HIP_TRY(hipStreamSynchronize(h->stream));
+  return BL_OK;
+}
+
+// bP_local = X_k' kappa_k, kappa_i = n_i (y_i - 1/2)   (Logit.hpp:174-183, this rank's rows)
+int bl_gibbs_set_bp_local(bl_gibbs* h)
+{
+  if (int rc = valid(h)) return rc;
+  if (!h->y && h->N > 0) {
+    blh::set_error("bl_gibbs_set_bp_local: y not set");
+    return BL_ERR_ARG;
+  }
+  blk::launch_colsum(h->tX, h->y, h->n, nullptr, nullptr, h->N, h->P, h->colws, h->bP, h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+// bP = b0 + (all-reduced) X' kappa
+int bl_gibbs_finish_bp(bl_gibbs* h)
+{
+  if (int rc = valid(h)) return rc;
+  blk::launch_vec_add(h->bP, h->bP, h->b0, h->P, h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_gibbs_sweep_local(bl_gibbs* h, uint32_t sweep, double* w_out)
+{
+  if (int rc = valid(h)) return rc;
+  blk::launch_sweep(h->plan, h->tX, h->n, h->beta, nullptr, w_out, h->wscr, h->N, h->partial, h->PP, h->seed, sweep,
+                    h->idx0, blk::W_DRAW, blh::status_word(h->stream), h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
+{
+  if (int rc = valid(h)) return rc;
+  blk::BetaArgs a;
+  a.P = h->P;
+  a.PPsum = h->PP;
+  a.P0 = h->P0;
+  a.bP = h->bP;
+  a.beta_prev = h->beta;
+  a.beta_out = h->beta;
+  a.work = h->work;
+  a.seed = h->seed;
+  a.epoch = sweep;
+  a.status = blh::status_word(h->stream);
+  blk::launch_beta(a, constrain ? blk::B_CONSTRAINED : blk::B_MVN, h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_gibbs_em_local(bl_gibbs* h)
+{
+  if (int rc = valid(h)) return rc;
+  blk::launch_sweep(h->plan, h->tX, h->n, h->beta, nullptr, nullptr, h->wscr, h->N, h->partial, h->PP, h->seed, 0,
+                    h->idx0, blk::W_EM, blh::status_word(h->stream), h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_gibbs_em_solve(bl_gibbs* h, double* dist_host)
+{
+  if (int rc = valid(h)) return rc;
+  BL_HIP_TRY(hipMemcpyAsync(h->beta_old, h->beta, sizeof(double) * h->P, hipMemcpyDeviceToDevice, h->stream));
+  blk::BetaArgs a;
+  a.P = h->P;
+  a.PPsum = h->PP;
+  a.P0 = h->P0;
+  a.bP = h->bP;
+  a.beta_prev = h->beta;
+  a.beta_out = h->beta;
+  a.work = h->work;
+  a.seed = h->seed;
+  a.epoch = 0;
+  a.status = blh::status_word(h->stream);
+  blk::launch_beta(a, blk::B_SOLVE, h->stream);
+  blk::launch_maxabsdiff(h->beta, h->beta_old, h->P, h->dist, h->stream);
+  BL_HIP_TRY(hipGetLastError());
+  if (dist_host) {
+    BL_HIP_TRY(hipMemcpyAsync(dist_host, h->dist, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    BL_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return BL_OK;
+}
+
+double* bl_gibbs_pp_ptr(bl_gibbs* h) { return h ? h->PP : nullptr; }
+double* bl_gibbs_bp_ptr(bl_gibbs* h) { return h ? h->bP : nullptr; }
+double* bl_gibbs_beta_ptr(bl_gibbs* h) { return h ? h->beta : nullptr; }
+
+int bl_gibbs_get_beta(bl_gibbs* h, double* beta_host)
+{
+  if (int rc = valid(h)) return rc;
+  BL_HIP_TRY(hipMemcpyAsync(beta_host, h->beta, sizeof(double) * h->P, hipMemcpyDeviceToHost, h->stream));
+  BL_HIP_TRY(hipStreamSynchronize(h->stream));
+  return BL_OK;
+}
+
+// Logit::gibbs, Logit.hpp:460-481: set_bP, a burn block that rewrites slot 0 `burn`
+// times, then `samp` sweeps writing one slot each.  beta_out is host P x samp.
+int bl_gibbs_run(bl_gibbs* h, int samp, int burn, int constrain, double* beta_out_host, double* w_out_dev)
+{
+  if (int rc = valid(h)) return rc;
+  if (samp < 1 || burn < 0) {
+    blh::set_error("bl_gibbs_run: need samp >= 1, burn >= 0");
+    return BL_ERR_ARG;
+  }
+  const int P = h->P;
+  double* hist = nullptr;
+  BL_HIP_TRY(hipMalloc((void**)&hist, sizeof(double) * (size_t)P * samp));
+  int rc = bl_gibbs_set_bp_local(h);
+  if (rc == BL_OK) rc = bl_gibbs_finish_bp(h);
+  hipError_t e = hipMemsetAsync(h->beta, 0, sizeof(double) * P, h->stream);   // chain starts at beta = 0
+  uint32_t sweep = 0;
+  for (int m = 0; rc == BL_OK && e == hipSuccess && m < burn; ++m, ++sweep) {
+    rc = bl_gibbs_sweep_local(h, sweep, w_out_dev);            // burn-in omega lands in slot 0
+    if (rc == BL_OK) rc = bl_gibbs_draw_beta(h, sweep, constrain);
+  }
+  for (int m = 0; rc == BL_OK && e == hipSuccess && m < samp; ++m, ++sweep) {
+    double* wslot = w_out_dev ? w_out_dev + (size_t)m * h->N : nullptr;
+    rc = bl_gibbs_sweep_local(h, sweep, wslot);
+    if (rc == BL_OK) rc = bl_gibbs_draw_beta(h, sweep, constrain);
+    if (rc == BL_OK)
+      e = hipMemcpyAsync(hist + (size_t)m * P, h->beta, sizeof(double) * P, hipMemcpyDeviceToDevice, h->stream);
+  }
+  if (rc == BL_OK && e == hipSuccess && beta_out_host)
+    e = hipMemcpyAsync(beta_out_host, hist, sizeof(double) * (size_t)P * samp, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(hist);
+  if (e != hipSuccess) {
+    blh::set_error(std::string("bl_gibbs_run: ") + hipGetErrorString(e));
+    return BL_ERR_HIP;
+  }
+  if (rc != BL_OK) return rc;
+  return blh::collect_status(h->stream);
+}
+
+// ================================================================ .C boundary
+// gibbs(), LogitWrapper.cpp:176-234
+void gibbs(double* wp, double* betap, double* yp, double* tXp, double* np, double* m0p, double* P0p, int* N, int* P,
+           int* samp, int* burn)
+{
+  if (!blh::ensure_device()) return;
+  const int64_t n = *N;
+  const int p = *P;
+  const uint64_t seed = blh::global_seed() ^ ((uint64_t)blh::next_epoch() << 40);
+  blh::DevBuf<double> dX, dy, dn, dw;
+  hipError_t e = dX.alloc((size_t)n * p);
+  if (e == hipSuccess) e = dy.alloc(n);
+  if (e == hipSuccess) e = dn.alloc(n);
+  if (e == hipSuccess) e = dw.alloc((size_t)n * *samp);
+  if (e == hipSuccess) e = dX.upload(tXp);
+  if (e == hipSuccess) e = dy.upload(yp);
+  if (e == hipSuccess) e = dn.upload(np);
+  if (e != hipSuccess) {
+    blh::set_error(std::string("gibbs: ") + hipGetErrorString(e));
+    printf("Aborting Gibbs sampler.\n");
+    return;
+  }
+  bl_gibbs* h = nullptr;
+  int rc = bl_gibbs_create(&h, n, p, 0, seed, nullptr);
+  if (rc == BL_OK) rc = bl_gibbs_set_data(h, dX.p, dy.p, dn.p);
+  if (rc == BL_OK) rc = bl_gibbs_set_prior(h, m0p, P0p);
+  if (rc == BL_OK) rc = bl_gibbs_run(h, *samp, *burn, blh::global_constrain(), betap, dw.p);
+  if (rc == BL_OK || rc == BL_ERR_SAMPLER) {
+    e = dw.download(wp);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) blh::set_error(std::string("gibbs: ") + hipGetErrorString(e));
+  } else {
+    printf("Error: %s\n", bl_last_error());
+    printf("Aborting Gibbs sampler.\n");
+  }
+  bl_gibbs_destroy(h);
+  *N = (int)n;   // rows after merge: gibbs() itself does not merge (LogitWrapper.cpp:204)
+}
+
+// EM(), LogitWrapper.cpp:238-273 / Logit::EM, Logit.hpp:488-554
+void EM(double* betap, double* yp, double* tXp, double* np, int* Np, int* Pp, double* tolp, int* max_iterp)
+{
+  if (!blh::ensure_device()) return;
+  const int64_t n = *Np;
+  const int p = *Pp;
+  blh::DevBuf<double> dX, dy, dn;
+  hipError_t e = dX.alloc((size_t)n * p);
+  if (e == hipSuccess) e = dy.alloc(n);
+  if (e == hipSuccess) e = dn.alloc(n);
+  if (e == hipSuccess) e = dX.upload(tXp);
+  if (e == hipSuccess) e = dy.upload(yp);
+  if (e == hipSuccess) e = dn.upload(np);
+  if (e != hipSuccess) {
+    blh::set_error(std::string("EM: ") + hipGetErrorString(e));
+    printf("Aborting EM.\n");
+    return;
+  }
+  bl_gibbs* h = nullptr;
+  int rc = bl_gibbs_create(&h, n, p, 0, 0, nullptr);   // pool is zeroed: P0 = 0, m0 = 0, beta = 0
+  if (rc == BL_OK) rc = bl_gibbs_set_data(h, dX.p, dy.p, dn.p);
+  if (rc == BL_OK) rc = bl_gibbs_set_bp_local(h);
+  if (rc == BL_OK) rc = bl_gibbs_finish_bp(h);
+  const double tol = *tolp;
+  const int max_iter = *max_iterp;
+  double dist = tol + 1.0;
+  int iter = 0;
+  while (rc == BL_OK && dist > tol && iter < max_iter) {
+    rc = bl_gibbs_em_local(h);
+    if (rc == BL_OK) rc = bl_gibbs_em_solve(h, &dist);
+    if (rc == BL_OK) rc = blh::collect_status(nullptr);
+    ++iter;
+  }
+  if (rc == BL_OK) {
+    rc = bl_gibbs_get_beta(h, betap);
+    *max_iterp = iter;
+  }
+  if (rc != BL_OK) {
+    printf("Error: %s\n", bl_last_error());
+    printf("Aborting EM.\n");
+  }
+  bl_gibbs_destroy(h);
+}
+
+// combine(), LogitWrapper.cpp:279-310 / Logit::compress, Logit.hpp:192-270
+void combine(double* yp, double* tXp, double* np, int* N, int* P)
+{
+  if (!blh::ensure_device()) return;
+  const int64_t n = *N;
+  const int p = *P;
+  if (n <= 0) return;
+  blh::DevBuf<double> dX, dy, dn;
+  hipError_t e = dX.alloc((size_t)n * p);
+  if (e == hipSuccess) e = dy.alloc(n);
+  if (e == hipSuccess) e = dn.alloc(n);
+  if (e == hipSuccess) e = dX.upload(tXp);
+  if (e == hipSuccess) e = dy.upload(yp);
+  if (e == hipSuccess) e = dn.upload(np);
+  int64_t m = n;
+  int rc = BL_ERR_HIP;
+  if (e == hipSuccess) rc = blk::combine_rows(dy.p, dX.p, dn.p, n, p, 1, &m, nullptr);
+  if (rc == BL_OK) {
+    e = hipMemcpy(yp, dy.p, sizeof(double) * m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tXp, dX.p, sizeof(double) * m * p, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(np, dn.p, sizeof(double) * m, hipMemcpyDeviceToHost);
+  }
+  if (rc != BL_OK || e != hipSuccess) {
+    printf("Error: %s\n", e != hipSuccess ? hipGetErrorString(e) : bl_last_error());
+    printf("Aborting combine.\n");
+    return;
+  }
+  if (m != n) {
+    printf("Warning: data was combined!\n");          // Logit.hpp:248-251
+    printf("N: %i, P: %i \n", (int)m, p);
+  }
+  *N = (int)m;
+}
+
+// mult_combine(), LogitWrapper.cpp:376-408 / MultLogit::set_data merge, MultLogit.hpp:137-208
+void mult_combine(double* typ, double* tXp, double* np, int* N, int* P, int* J)
+{
+  if (!blh::ensure_device()) return;
+  const int64_t n = *N;
+  const int p = *P, u = *J - 1;
+  if (n <= 0 || u < 1) return;
+  blh::DevBuf<double> dX, dy, dn;
+  hipError_t e = dX.alloc((size_t)n * p);
+  if (e == hipSuccess) e = dy.alloc((size_t)n * u);
+  if (e == hipSuccess) e = dn.alloc(n);
+  if (e == hipSuccess) e = dX.upload(tXp);
+  if (e == hipSuccess) e = dy.upload(typ);
+  if (e == hipSuccess) e = dn.upload(np);
+  int64_t m = n;
+  int rc = BL_ERR_HIP;
+  if (e == hipSuccess) rc = blk::combine_rows(dy.p, dX.p, dn.p, n, p, u, &m, nullptr);
+  if (rc == BL_OK) {
+    e = hipMemcpy(typ, dy.p, sizeof(double) * m * u, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tXp, dX.p, sizeof(double) * m * p, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(np, dn.p, sizeof(double) * m, hipMemcpyDeviceToHost);
+  }
+  if (rc != BL_OK || e != hipSuccess) {
+    printf("Error: %s\n", e != hipSuccess ? hipGetErrorString(e) : bl_last_error());
+    printf("Aborting combine.\n");
+    return;
+  }
+  if (m != n) {
+    printf("Warning: data was combined!\n");
+    printf("N: %i, P: %i \n", (int)m, p);
+  }
+  *N = (int)m;
+}
+
+// mult_gibbs(), LogitWrapper.cpp:316-374 / MultLogit::gibbs, MultLogit.hpp:261-372.
+// Data are taken as given (mlogit() merges through mlogit.combine first,
+// LogitWrapper.R:371-377; the constructor's own merge is then a no-op).
+void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np, double* m0p, double* P0p, int* N,
+                int* P, int* J, int* sampp, int* burnp)
+{
+  if (!blh::ensure_device()) return;
+  const int64_t n = *N;
+  const int p = *P, u = *J - 1, samp = *sampp, burn = *burnp;
+  if (u < 1 || samp < 1 || burn < 0 || p < 1) {
+    printf("Error: mult_gibbs: bad arguments\nAborting Gibbs sampler.\n");
+    return;
+  }
+  const uint64_t seed = blh::global_seed() ^ ((uint64_t)blh::next_epoch() << 40);
+  hipStream_t s = nullptr;
+  const size_t PPn = (size_t)p * p;
+  blh::DevBuf<double> dX, dty, dn, dw, dbeta, dXB, dc, dZ, db0, dP0, dm0, dkap, db1, dxoc;
+  hipError_t e = dX.alloc((size_t)n * p);
+  if (e == hipSuccess) e = dty.alloc((size_t)n * u);
+  if (e == hipSuccess) e = dn.alloc(n);
+  if (e == hipSuccess) e = dw.alloc((size_t)n * u * samp);
+  if (e == hipSuccess) e = dbeta.alloc((size_t)p * u * samp);
+  if (e == hipSuccess) e = dXB.alloc((size_t)n * (u + 1));
+  if (e == hipSuccess) e = dc.alloc(n);
+  if (e == hipSuccess) e = dZ.alloc((size_t)p * u);
+  if (e == hipSuccess) e = db0.alloc((size_t)p * u);
+  if (e == hipSuccess) e = dP0.alloc(PPn * u);
+  if (e == hipSuccess) e = dm0.alloc((size_t)p * u);
+  if (e == hipSuccess) e = dkap.alloc(n);
+  if (e == hipSuccess) e = db1.alloc(p);
+  if (e == hipSuccess) e = dxoc.alloc(p);
+  if (e == hipSuccess) e = dX.upload(tXp);
+  if (e == hipSuccess) e = dty.upload(typ);
+  if (e == hipSuccess) e = dn.upload(np);
+  if (e == hipSuccess) e = dP0.upload(P0p);
+  if (e == hipSuccess) e = dm0.upload(m0p);
+  if (e == hipSuccess) e = hipMemset(dXB.p, 0, sizeof(double) * (size_t)n * (u + 1));
+  if (e == hipSuccess) e = hipMemset(dbeta.p, 0, sizeof(double) * (size_t)p * u * samp);
+  if (e != hipSuccess) {
+    blh::set_error(std::string("mult_gibbs: ") + hipGetErrorString(e));
+    printf("Aborting Gibbs sampler.\n");
+    return;
+  }
+  bl_gibbs* h = nullptr;
+  int rc = bl_gibbs_create(&h, n, p, 0, seed, s);
+  if (rc == BL_OK) rc = bl_gibbs_set_data(h, dX.p, nullptr, dn.p);
+  // y (U x N, category fastest) -> per-category rows for kappa: Z_j = X' (n (y_j - 1/2)), MultLogit.hpp:214-219
+  std::vector<double> yj((size_t)(n > 0 ? n : 1));
+  blh::DevBuf<double> dyj;
+  if (rc == BL_OK && dyj.alloc(n) != hipSuccess) rc = BL_ERR_HIP;
+  for (int j = 0; rc == BL_OK && j < u; ++j) {
+    for (int64_t i = 0; i < n; ++i) yj[i] = typ[(size_t)i * u + j];
+    if (dyj.upload(yj.data()) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = BL_ERR_HIP; break; }
+    blk::launch_colsum(dX.p, dyj.p, dn.p, nullptr, nullptr, n, p, h->colws, dZ.p + (size_t)j * p, s);
+    blk::launch_matvec(db0.p + (size_t)j * p, dP0.p + (size_t)j * PPn, dm0.p + (size_t)j * p, p, s);   // b0_j = P0_j m0_j
+  }
+  const int total = burn + samp;   // burn+1 sweeps into slot 0, then samp-1 more (MultLogit.hpp:284,332)
+  for (int sw = 0; rc == BL_OK && sw < total; ++sw) {
+    const int slot = sw <= burn ? 0 : sw - burn;
+    double* bslot = dbeta.p + (size_t)slot * p * u;
+    double* wslot = dw.p + (size_t)slot * n * u;
+    for (int j = 0; j < u; ++j) {
+      const uint32_t epoch = (uint32_t)sw * (uint32_t)u + (uint32_t)j;
+      double* bj = bslot + (size_t)j * p;
+      // current beta_j lives in XB; the kernel needs beta_j itself: it is the last value written for j
+      const double* bcur = (sw == 0) ? bj : (dbeta.p + (size_t)(sw <= burn ? 0 : slot - 1) * p * u + (size_t)j * p);
+      blk::launch_mlogit_offset(dXB.p, n, u + 1, j, dc.p, s);                       // c_j
+      blk::launch_sweep(h->plan, dX.p, dn.p, bcur, dc.p, wslot + (size_t)j * n, h->wscr, n, h->partial, h->PP, seed,
+                        epoch, 0, blk::W_DRAW, blh::status_word(s), s);             // eta = XB_j - c_j ; omega ; X'OmX
+      blk::launch_colsum(dX.p, nullptr, nullptr, wslot + (size_t)j * n, dc.p, n, p, h->colws, dxoc.p, s);   // X' Om c_j
+      blk::launch_vec_add(db1.p, dZ.p + (size_t)j * p, dxoc.p, p, s);
+      blk::launch_vec_add(db1.p, db1.p, db0.p + (size_t)j * p, p, s);              // b1 = Z_j + X'Om c_j + b0_j
+      blk::BetaArgs a;
+      a.P = p;
+      a.PPsum = h->PP;
+      a.P0 = dP0.p + (size_t)j * PPn;
+      a.bP = db1.p;
+      a.beta_prev = bcur;
+      a.beta_out = bj;
+      a.work = h->work;
+      a.seed = seed;
+      a.epoch = epoch;
+      a.status = blh::status_word(s);
+      blk::launch_beta(a, blk::B_FROM_LIK, s);
+      blk::launch_xbeta(dX.p, bj, n, p, dXB.p + (size_t)j * n, s);                 // XB_j = X beta_j
+    }
+    if (hipGetLastError() != hipSuccess) rc = BL_ERR_HIP;
+  }
+  if (rc == BL_OK) rc = blh::collect_status(s);
+  if (rc == BL_OK || rc == BL_ERR_SAMPLER) {
+    e = dw.download(wp);
+    if (e == hipSuccess) e = dbeta.download(betap);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) blh::set_error(std::string("mult_gibbs: ") + hipGetErrorString(e));
+  } else {
+    printf("Error: %s\n", bl_last_error());
+    printf("Aborting Gibbs sampler.\n");
+  }
+  bl_gibbs_destroy(h);
+  *N = (int)n;
+}
+
+}  // extern "C"

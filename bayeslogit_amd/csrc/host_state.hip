@@ -1,0 +1,138 @@
+// host_state.hip -- process-global state of libbayeslogit_hip.so: last error text,
+// sampler status word, seed/epoch of the .C-style entry points.
+#include "bl_host.hpp"
+
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+
+namespace {
+std::mutex g_mu;
+std::string g_err;
+int g_flags = 0;
+uint64_t initial_seed()
+{
+  if (const char* s = getenv("BAYESLOGIT_SEED")) return strtoull(s, nullptr, 0);
+  return 0x42A7E5105EEDull;
+}
+std::atomic<uint64_t> g_seed{initial_seed()};
+std::atomic<uint32_t> g_epoch{0};
+std::atomic<int> g_constrain{1};
+int* g_status_dev = nullptr;
+bool g_dev_ok = false, g_dev_tried = false;
+}  // namespace
+
+namespace blh {
+
+void set_error(const std::string& msg)
+{
+  std::lock_guard<std::mutex> l(g_mu);
+  g_err = msg;
+  fprintf(stderr, "bayeslogit_hip: %s\n", msg.c_str());
+}
+
+bool ensure_device()
+{
+  std::lock_guard<std::mutex> l(g_mu);
+  if (g_dev_tried) return g_dev_ok;
+  g_dev_tried = true;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n < 1) {
+    g_err = "no HIP device available (libbayeslogit_hip has no CPU fallback)";
+    fprintf(stderr, "bayeslogit_hip: %s\n", g_err.c_str());
+    return false;
+  }
+  e = hipMalloc((void**)&g_status_dev, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(g_status_dev, 0, sizeof(int));
+  if (e != hipSuccess) {
+    g_err = std::string("hipMalloc(status): ") + hipGetErrorString(e);
+    fprintf(stderr, "bayeslogit_hip: %s\n", g_err.c_str());
+    return false;
+  }
+  g_dev_ok = true;
+  return true;
+}
+
+int* status_word(hipStream_t) { return g_status_dev; }
+
+int collect_status(hipStream_t s)
+{
+  int st = 0;
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipMemcpy(&st, g_status_dev, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && st != 0) e = hipMemset(g_status_dev, 0, sizeof(int));
+  if (e != hipSuccess) {
+    set_error(std::string("status sync: ") + hipGetErrorString(e));
+    return BL_ERR_HIP;
+  }
+  {
+    std::lock_guard<std::mutex> l(g_mu);
+    g_flags = st;
+  }
+  if (st != 0) {
+    set_error("sampler flags raised: " + std::to_string(st) +
+              " (1 = iteration cap, 2 = bad shape, 4 = alt sampler fall-through)");
+    return BL_ERR_SAMPLER;
+  }
+  return BL_OK;
+}
+
+uint64_t global_seed() { return g_seed.load(); }
+uint32_t next_epoch() { return g_epoch.fetch_add(1); }
+int global_constrain() { return g_constrain.load(); }
+
+}  // namespace blh
+
+extern "C" {
+
+const char* bl_last_error(void)
+{
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> l(g_mu);
+  copy = g_err;
+  return copy.c_str();
+}
+
+int bl_last_sampler_flags(void)
+{
+  std::lock_guard<std::mutex> l(g_mu);
+  return g_flags;
+}
+
+int bl_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int bl_set_device(int device)
+{
+  if (g_dev_tried && g_dev_ok) {
+    blh::set_error("bl_set_device must be called before any other entry point");
+    return BL_ERR_ARG;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    blh::set_error("hipSetDevice failed");
+    return BL_ERR_NO_DEVICE;
+  }
+  return blh::ensure_device() ? BL_OK : BL_ERR_NO_DEVICE;
+}
+
+void bl_set_seed(uint64_t seed)
+{
+  g_seed = seed;
+  g_epoch = 0;
+}
+uint64_t bl_get_seed(void) { return g_seed.load(); }
+uint32_t bl_get_epoch(void) { return g_epoch.load(); }
+void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
+
+int bl_sync_status(void* stream)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  return blh::collect_status((hipStream_t)stream);
+}
+
+}  // extern "C"

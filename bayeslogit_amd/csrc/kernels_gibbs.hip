@@ -1,0 +1,821 @@
+// kernels_gibbs.hip -- kernels of the logistic Gibbs sweep on MI355X (gfx950):
+//   * k_sweep_fused<NB,MODE>: ONE pass over this rank's rows of X per sweep --
+//     psi = X beta, omega ~ PG(n, psi) one draw per lane, and the symmetric
+//     rank-N update X' Omega X on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64),
+//     with the 64-row tile held in registers between the two uses.
+//     Replaces gemm(psi) + draw_w + the P x N temp + syrk of Logit.hpp:283-301,431.
+//   * generic fallbacks for shapes the fused kernel does not take (P not a
+//     multiple of 16, or P > 64): k_psi_omega + k_xwx_tiles.
+//   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
+//   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
+#include "bl_gibbs_kernels.hpp"
+#include "bl_pg_devroye.hpp"
+#include "../../include/bayeslogit_hip.h"
+
+namespace {
+
+using namespace bl;
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;
+
+// omega for one observation
+template <int MODE>
+__device__ __forceinline__ double weight_of(double psi, double n, uint64_t seed, uint64_t idx, uint32_t epoch, int& st)
+{
+  if (MODE == blk::W_DRAW) {
+    Stream r;
+    r.init(seed, idx, DOM_DRAW, epoch);
+    return pg_draw_devroye((int)n, psi, r, st);        // Logit.hpp:287
+  } else {
+    const double hpsi = psi * 0.5;                      // Logit.hpp:509-519
+    if (fabs(hpsi) < 0.01)
+      return n / cosh(hpsi) * (1 + hpsi * hpsi / 6.0 + pow(hpsi, 4.0) / 120.0 + pow(hpsi, 6) / 5040.0) * 0.25;
+    return n * tanh(hpsi) / hpsi * 0.25;
+  }
+}
+
+// ============================================================ fused sweep kernel
+// Column of X held by lane-column c in MFMA block q.  The assignment is chosen so
+// that a lane's loads are 16-byte vectors and a wavefront's load instruction covers
+// whole 128-byte lines; PP is un-permuted in the reduction epilogue.
+template <int NB>
+__device__ __host__ __forceinline__ int colmap(int q, int c)
+{
+  if (NB == 1) return c;
+  if (NB == 2) return 2 * c + q;
+  if (NB == 3) return q < 2 ? 2 * c + q : 32 + c;
+  return (q >> 1) * 32 + 2 * c + (q & 1);
+}
+
+template <int NB>
+struct Tile {
+  double x[16][NB];   // [group of 4 rows][block]; statically indexed => registers
+};
+
+template <int NB>
+__device__ __forceinline__ void load_tile(Tile<NB>& t, const double* __restrict__ tX, int64_t tile, int64_t N, int k,
+                                          int c)
+{
+  constexpr int P = 16 * NB;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int64_t row = tile * 64 + 4 * g + k;
+    const bool ok = row < N;
+    const double* p = tX + (size_t)(ok ? row : 0) * P;
+    if (NB == 1) {
+      const double v = p[c];
+      t.x[g][0] = ok ? v : 0.0;
+    } else {
+      const v2d v0 = *reinterpret_cast<const v2d*>(p + 2 * c);
+      t.x[g][0] = ok ? v0.x : 0.0;
+      t.x[g][1] = ok ? v0.y : 0.0;
+      if (NB == 3) {
+        const double v = p[32 + c];
+        t.x[g][2] = ok ? v : 0.0;
+      }
+      if (NB == 4) {
+        const v2d v1 = *reinterpret_cast<const v2d*>(p + 32 + 2 * c);
+        t.x[g][2] = ok ? v1.x : 0.0;
+        t.x[g][3] = ok ? v1.y : 0.0;
+      }
+    }
+  }
+}
+
+template <int NB>
+struct Acc {
+  v4d a[NB * (NB + 1) / 2];
+};
+
+// psi for the lane's own observation (row 4c+k of the tile), then omega, then the
+// rank-64 update of the accumulators.
+template <int NB, int MODE>
+__device__ __forceinline__ void process_tile(const Tile<NB>& t, Acc<NB>& acc, const double (&bq)[NB], int64_t tile,
+                                             int64_t N, int lane, int k, int c, const double* __restrict__ nvec,
+                                             const double* __restrict__ off, double* __restrict__ w_store,
+                                             uint64_t seed, uint32_t epoch, uint64_t idx0, int& st)
+{
+  double psi = 0.0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    double part = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) part += t.x[g][q] * bq[q];
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    part += __shfl_xor(part, 8);
+    psi = (c == g) ? part : psi;
+  }
+  const int64_t row = tile * 64 + 4 * c + k;
+  double omega = 0.0;
+  if (row < N) {
+    if (off) psi -= off[row];
+    omega = weight_of<MODE>(psi, nvec[row], seed, idx0 + (uint64_t)row, epoch, st);
+    if (w_store) w_store[row] = omega;
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const double wg = __shfl(omega, (lane & 48) | g);
+    double a[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) a[q] = wg * t.x[g][q];
+    int blkid = 0;
+#pragma unroll
+    for (int qa = 0; qa < NB; ++qa)
+#pragma unroll
+      for (int qb = qa; qb < NB; ++qb) {
+        acc.a[blkid] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], t.x[g][qb], acc.a[blkid], 0, 0, 0);
+        ++blkid;
+      }
+  }
+}
+
+// One workgroup = 4 wavefronts, one per SIMD, each streaming its own 64-row tiles:
+// wave w of block b takes tiles w_global, w_global + W, ... (W = 4 * gridDim.x).
+// The next tile's loads are issued before the current tile's draw + MFMA phases so
+// HBM latency hides under them (two register tiles, ping-pong).
+template <int NB, int MODE>
+__global__ __launch_bounds__(kBlock, 1) void k_sweep_fused(const double* __restrict__ tX,
+                                                           const double* __restrict__ nvec,
+                                                           const double* __restrict__ beta,
+                                                           const double* __restrict__ off,
+                                                           double* __restrict__ w_store, int64_t N,
+                                                           double* __restrict__ partial, uint64_t seed,
+                                                           uint32_t epoch, uint64_t idx0, int* __restrict__ status)
+{
+  constexpr int NBLK = NB * (NB + 1) / 2;
+  __shared__ double red[4][NBLK * 4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane >> 4, c = lane & 15;
+  const int64_t ntiles = (N + 63) / 64;
+  const int64_t W = (int64_t)gridDim.x * 4;
+  int st = 0;
+
+  double bq[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) bq[q] = beta[colmap<NB>(q, c)];
+
+  Acc<NB> acc;
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) acc.a[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  Tile<NB> ta, tb;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile < ntiles) load_tile<NB>(ta, tX, tile, N, k, c);
+  while (tile < ntiles) {
+    if (tile + W < ntiles) load_tile<NB>(tb, tX, tile + W, N, k, c);
+    process_tile<NB, MODE>(ta, acc, bq, tile, N, lane, k, c, nvec, off, w_store, seed, epoch, idx0, st);
+    tile += W;
+    if (tile >= ntiles) break;
+    if (tile + W < ntiles) load_tile<NB>(ta, tX, tile + W, N, k, c);
+    process_tile<NB, MODE>(tb, acc, bq, tile, N, lane, k, c, nvec, off, w_store, seed, epoch, idx0, st);
+    tile += W;
+  }
+
+  // fixed-order in-block reduction of the four waves' accumulators
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][b * 4 + r][lane] = acc.a[b][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < NBLK * 4 * 64; e += kBlock) {
+    const int rr = e >> 6, ll = e & 63;
+    const double s = ((red[0][rr][ll] + red[1][rr][ll]) + red[2][rr][ll]) + red[3][rr][ll];
+    partial[(size_t)blockIdx.x * (NBLK * 4 * 64) + e] = s;
+  }
+  if (st) atomicOr(status, st);
+}
+
+// PP = sum over workgroups (fixed order) of the permuted MFMA blocks; un-permute,
+// take the i <= j half of diagonal blocks, mirror: PP is exactly symmetric.
+template <int NB>
+__global__ __launch_bounds__(kBlock) void k_reduce_fused(const double* __restrict__ partial, int nparts,
+                                                         double* __restrict__ PP)
+{
+  constexpr int P = 16 * NB;
+  constexpr int NBLK = NB * (NB + 1) / 2;
+  constexpr int E = NBLK * 4 * 64;
+  __shared__ double sm[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int s = threadIdx.x >> 6;
+  double sum = 0.0;
+  if (e < E)
+    for (int b = s; b < nparts; b += 4) sum += partial[(size_t)b * E + e];
+  sm[s][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (s == 0 && e < E) {
+    const int l = threadIdx.x & 63;
+    const double tot = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    const int blkid = e / 256, reg = (e >> 6) & 3, ln = e & 63;
+    int qa = 0, qb = 0, id = 0;
+    for (int a = 0; a < NB; ++a)
+      for (int b = a; b < NB; ++b) {
+        if (id == blkid) { qa = a; qb = b; }
+        ++id;
+      }
+    const int i = (ln >> 4) + 4 * reg, j = ln & 15;
+    const int A = colmap<NB>(qa, i), B = colmap<NB>(qb, j);
+    if (qa != qb || i <= j) {
+      PP[A + (size_t)B * P] = tot;
+      PP[B + (size_t)A * P] = tot;
+    }
+  }
+}
+
+// ======================================================= generic (any P) kernels
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_psi_omega(const double* __restrict__ tX, const double* __restrict__ nvec,
+                                                      const double* __restrict__ beta,
+                                                      const double* __restrict__ off, double* __restrict__ w_store,
+                                                      int64_t N, int P, uint64_t seed, uint32_t epoch,
+                                                      uint64_t idx0, int* __restrict__ status)
+{
+  extern __shared__ double sbeta[];
+  for (int j = threadIdx.x; j < P; j += kBlock) sbeta[j] = beta[j];
+  __syncthreads();
+  int st = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+    const double* xr = tX + (size_t)i * P;
+    double s = 0.0;
+    for (int j = 0; j < P; ++j) s += xr[j] * sbeta[j];
+    if (off) s -= off[i];
+    w_store[i] = weight_of<MODE>(s, nvec[i], seed, idx0 + (uint64_t)i, epoch, st);
+  }
+  if (st) atomicOr(status, st);
+}
+
+// partial[chunk][tile][64x64] = sum over the chunk's rows of w_i x_i[A-tile] x_i[B-tile]'
+constexpr int kRows = 32;
+__global__ __launch_bounds__(kBlock) void k_xwx_tiles(const double* __restrict__ tX, const double* __restrict__ w,
+                                                      int64_t N, int P, int T, int64_t rows_per_chunk,
+                                                      double* __restrict__ partial)
+{
+  __shared__ double xa[kRows][64];
+  __shared__ double xb[kRows][64];
+  int ta = 0, tb = 0;
+  {
+    int id = 0;
+    for (int a = 0; a < T; ++a)
+      for (int b = a; b < T; ++b) {
+        if (id == (int)blockIdx.y) { ta = a; tb = b; }
+        ++id;
+      }
+  }
+  const int a = threadIdx.x & 63, bq = threadIdx.x >> 6;
+  double acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  const int64_t r1 = (r0 + rows_per_chunk < N) ? r0 + rows_per_chunk : N;
+  for (int64_t rb = r0; rb < r1; rb += kRows) {
+    for (int e = threadIdx.x; e < kRows * 64; e += kBlock) {
+      const int r = e >> 6, cc = e & 63;
+      const int64_t row = rb + r;
+      const bool rok = row < r1;
+      const int ca = 64 * ta + cc, cb = 64 * tb + cc;
+      const double wr = rok ? w[row] : 0.0;
+      xa[r][cc] = (rok && ca < P) ? tX[(size_t)row * P + ca] * wr : 0.0;
+      xb[r][cc] = (rok && cb < P) ? tX[(size_t)row * P + cb] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < kRows; ++r) {
+      const double va = xa[r][a];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] += va * xb[r][bq + 4 * q];
+    }
+    __syncthreads();
+  }
+  double* out = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4096;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out[a + 64 * (bq + 4 * q)] = acc[q];
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_tiles(const double* __restrict__ partial, int nchunks, int P,
+                                                         int T, double* __restrict__ PP)
+{
+  const int ntile = T * (T + 1) / 2;
+  const int64_t total = (int64_t)ntile * 4096;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int tile = (int)(e / 4096), w = (int)(e % 4096);
+    int ta = 0, tb = 0, id = 0;
+    for (int a = 0; a < T; ++a)
+      for (int b = a; b < T; ++b) {
+        if (id == tile) { ta = a; tb = b; }
+        ++id;
+      }
+    const int A = 64 * ta + (w & 63), B = 64 * tb + (w >> 6);
+    if (A >= P || B >= P) continue;
+    if (ta == tb && A > B) continue;   // take the upper half of diagonal tiles, mirror below
+    double s = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) s += partial[((size_t)ch * ntile + tile) * 4096 + w];
+    PP[A + (size_t)B * P] = s;
+    PP[B + (size_t)A * P] = s;
+  }
+}
+
+// out_partial[blk][j] = sum over the block's rows of wgt_i x_ij  (deterministic)
+__global__ __launch_bounds__(kBlock) void k_colsum(const double* __restrict__ tX, const double* __restrict__ y,
+                                                   const double* __restrict__ nvec, const double* __restrict__ w,
+                                                   const double* __restrict__ cvec, int64_t N, int P,
+                                                   int64_t rows_per_block, double* __restrict__ ws)
+{
+  extern __shared__ double sm[];   // [rowlanes][P]
+  const int cols = P < kBlock ? P : kBlock;
+  const int rowlanes = kBlock / cols;
+  const int rl = threadIdx.x / cols, cl = threadIdx.x % cols;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+  for (int j0 = 0; j0 < P; j0 += cols) {
+    const int j = j0 + cl;
+    double s = 0.0;
+    if (rl < rowlanes && j < P)
+      for (int64_t i = r0 + rl; i < r1; i += rowlanes) {
+        const double wgt = w ? w[i] * (cvec ? cvec[i] : 1.0) : nvec[i] * (y[i] - 0.5);
+        s += tX[(size_t)i * P + j] * wgt;
+      }
+    if (rl < rowlanes && j < P) sm[rl * P + j] = s;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < P; j += kBlock) {
+    double s = 0.0;
+    for (int q = 0; q < rowlanes; ++q) s += sm[q * P + j];
+    ws[(size_t)blockIdx.x * P + j] = s;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_colsum_reduce(const double* __restrict__ ws, int nblk, int P,
+                                                          double* __restrict__ out)
+{
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < P; j += gridDim.x * kBlock) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * P + j];
+    out[j] = s;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_xbeta(const double* __restrict__ tX, const double* __restrict__ beta,
+                                                  int64_t N, int P, double* __restrict__ out)
+{
+  extern __shared__ double sbeta[];
+  for (int j = threadIdx.x; j < P; j += kBlock) sbeta[j] = beta[j];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+    const double* xr = tX + (size_t)i * P;
+    double s = 0.0;
+    for (int j = 0; j < P; ++j) s += xr[j] * sbeta[j];
+    out[i] = s;
+  }
+}
+
+// MultLogit.hpp:293-299: A = rowSums(exp(XB_no_j)); c_j = log A
+__global__ __launch_bounds__(kBlock) void k_mlogit_offset(const double* __restrict__ XB, int64_t N, int J, int j,
+                                                          double* __restrict__ c_out)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+    double A = 0.0;
+    for (int k = 0; k < J; ++k)
+      if (k != j) A += exp(XB[(size_t)k * N + i]);
+    c_out[i] = log(A);
+  }
+}
+
+// ================================================================ P x P stage
+#define M_(M, i, j) ((M)[(size_t)(i) + (size_t)(j) * (size_t)P])
+
+// In-place A = U'U (upper triangle holds U), right-looking, whole workgroup.
+__device__ bool wg_chol_upper(double* A, int P, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = M_(A, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) M_(A, k, k) = d;
+    for (int j = k + 1 + t; j < P; j += kBlock) M_(A, k, j) = M_(A, k, j) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i <= j) M_(A, i, j) -= M_(A, k, i) * M_(A, k, j);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// In-place S = L L' (lower triangle holds L; strict upper zeroed).
+__device__ bool wg_chol_lower(double* S, int P, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = M_(S, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) M_(S, k, k) = d;
+    for (int i = k + 1 + t; i < P; i += kBlock) M_(S, i, k) = M_(S, i, k) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i >= j) M_(S, i, j) -= M_(S, i, k) * M_(S, j, k);
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    if (i < j) M_(S, i, j) = 0.0;
+  }
+  __syncthreads();
+  return true;
+}
+
+// B (P x nrhs, leading dim ldb) <- U'^{-1} B : forward substitution, all columns at once
+__device__ void wg_solve_Ut(const double* U, double* B, int P, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    const double d = M_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + (size_t)c * ldb] /= d;
+    __syncthreads();
+    const int m = P - i - 1;
+    for (int e = t; e < m * nrhs; e += kBlock) {
+      const int j = i + 1 + e % m, c = e / m;
+      B[j + (size_t)c * ldb] -= M_(U, i, j) * B[i + (size_t)c * ldb];
+    }
+    __syncthreads();
+  }
+}
+// B <- U^{-1} B : backward substitution
+__device__ void wg_solve_U(const double* U, double* B, int P, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = P - 1; i >= 0; --i) {
+    const double d = M_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + (size_t)c * ldb] /= d;
+    __syncthreads();
+    for (int e = t; e < i * nrhs; e += kBlock) {
+      const int j = e % i, c = e / i;
+      B[j + (size_t)c * ldb] -= M_(U, j, i) * B[i + (size_t)c * ldb];
+    }
+    __syncthreads();
+  }
+}
+// b <- L^{-1} b : forward substitution, single rhs
+__device__ void wg_solve_L(const double* L, double* b, int P)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    if (t == 0) b[i] /= M_(L, i, i);
+    __syncthreads();
+    for (int j = i + 1 + t; j < P; j += kBlock) b[j] -= M_(L, j, i) * b[i];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+  for (int m = 32; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+  for (int m = 32; m > 0; m >>= 1) v = fmin(v, __shfl_xor(v, m));
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
+{
+  extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
+  const int P = a.P, t = threadIdx.x;
+  double* A = a.work;                      // PP, then U
+  double* S = a.work + (size_t)P * P;      // PP^{-1}
+  double* mP = a.work + 2 * (size_t)P * P; // posterior mean
+  double* zz = mP + P;
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  for (int e = t; e < P * P; e += kBlock) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
+  __syncthreads();
+  if (!wg_chol_upper(A, P, &bad)) {
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, 8);
+    return;
+  }
+
+  if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
+    for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+    if (mode == blk::B_MVN && t < P) {
+      // eps_i = r.norm(0,1), i = 0..P-1 in stream order: normal i is exactly block i
+      Stream r;
+      r.init(a.seed, 0, DOM_BETA, a.epoch);
+      for (int i = t; i < P; i += kBlock) {
+        r.blk = (uint32_t)i;
+        r.has = false;
+        zz[i] = r.norm(0.0, 1.0);
+      }
+    }
+    __syncthreads();
+    wg_solve_Ut(A, mP, P, 1, P);
+    wg_solve_U(A, mP, P, 1, P);
+    if (mode == blk::B_MVN) {
+      wg_solve_U(A, zz, P, 1, P);
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = zz[j] + mP[j];
+    } else {
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = mP[j];
+    }
+    return;
+  }
+
+  // S = PP^{-1}: two triangular solves on the identity
+  for (int e = t; e < P * P; e += kBlock) S[e] = (e % P == e / P) ? 1.0 : 0.0;
+  __syncthreads();
+  wg_solve_Ut(A, S, P, P, P);
+  wg_solve_U(A, S, P, P, P);
+
+  if (mode == blk::B_FROM_LIK) {
+    // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps   (Normal.hpp:98-131)
+    for (int i = t; i < P; i += kBlock) {
+      double s = 0.0;
+      for (int k2 = 0; k2 < P; ++k2) s += M_(S, i, k2) * a.bP[k2];
+      mP[i] = s;
+    }
+    if (t < P) {
+      Stream r;
+      r.init(a.seed, 0, DOM_BETA, a.epoch);
+      for (int i = t; i < P; i += kBlock) {
+        r.blk = (uint32_t)i;
+        r.has = false;
+        zz[i] = r.norm(0.0, 1.0);
+      }
+    }
+    __syncthreads();
+    if (!wg_chol_lower(S, P, &bad)) {
+      __syncthreads();
+      if (t == 0) atomicOr(a.status, 8);
+      return;
+    }
+    for (int i = t; i < P; i += kBlock) {
+      double le = 0.0;
+      for (int k2 = 0; k2 <= i; ++k2) le += M_(S, i, k2) * zz[k2];
+      a.beta_out[i] = le + mP[i];
+    }
+    return;
+  }
+
+  // ---- B_CONSTRAINED: Logit.hpp:322-400 ----
+  for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+  __syncthreads();
+  wg_solve_Ut(A, mP, P, 1, P);
+  wg_solve_U(A, mP, P, 1, P);
+  if (!wg_chol_lower(S, P, &bad)) {     // L = chol(S,'L'), in place
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, 8);
+    return;
+  }
+  const bool l_in_lds = (size_t)P * P * 8 <= 128 * 1024;
+  double* Lm = l_in_lds ? lds : S;
+  double* sbeta = l_in_lds ? lds + (size_t)P * P : a.work + 2 * (size_t)P * P + 2 * P;
+  double* sz = sbeta + P;
+  int* perm = reinterpret_cast<int*>(sz + P);
+  if (l_in_lds)
+    for (int e = t; e < P * P; e += kBlock) Lm[e] = S[e];
+  for (int j = t; j < P; j += kBlock) {
+    zz[j] = a.beta_prev[j] - mP[j];     // z = beta_prev - mP
+    sbeta[j] = a.beta_prev[j];
+    perm[j] = j;
+  }
+  __syncthreads();
+  wg_solve_L(S, zz, P);                 // z = L^{-1} z
+  for (int j = t; j < P; j += kBlock) sz[j] = zz[j];
+  __syncthreads();
+
+  if (t < 64) {                          // one wavefront runs the serial coordinate sweeps
+    const int lane = t;
+    Stream r;
+    r.init(a.seed, 0, DOM_BETA, a.epoch);
+    const double inf = __builtin_huge_val();
+    for (int k = 0; k < P; ++k) {
+      for (int i = 0; i < P - 1; ++i) {          // random sweep order, :375-377
+        const int j = (int)(unsigned)r.flat((double)i, (double)P);
+        if (lane == 0) {
+          const int tmp = perm[i];
+          perm[i] = perm[j];
+          perm[j] = tmp;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < P; ++i) {              // :380-398
+        const int c = perm[i];
+        const double z1 = sz[c];
+        double lo = -inf, hi = inf;
+        for (int j = c + lane; j < P - 1; j += 64) {
+          const double l1 = M_(Lm, j, c);
+          const double c1 = z1 - sbeta[j] / l1;
+          if (l1 > 0.0 && c1 > lo) lo = c1;
+          else if (l1 < 0.0 && c1 < hi) hi = c1;
+        }
+        const double cmin = wave_max(lo), cmax = wave_min(hi);
+        const double z2 = tnorm(r, cmin, cmax);
+        const double dz = z2 - z1;
+        for (int j = c + lane; j < P; j += 64) sbeta[j] += M_(Lm, j, c) * dz;
+        if (lane == 0) sz[c] = z2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = t; j < P; j += kBlock) a.beta_out[j] = sbeta[j];
+}
+
+__global__ void k_maxabsdiff(const double* a, const double* b, int P, double* out)
+{
+  __shared__ double sm[kBlock];
+  double m = 0.0;
+  for (int j = threadIdx.x; j < P; j += kBlock) m = fmax(m, fabs(a[j] - b[j]));
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
+}
+
+__global__ void k_vec_add(double* dst, const double* a, const double* b, int P)
+{
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x)
+    dst[j] = a[j] + (b ? b[j] : 0.0);
+}
+
+__global__ void k_matvec(double* dst, const double* M, const double* v, int P)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int j = 0; j < P; ++j) s += M_(M, i, j) * v[j];
+    dst[i] = s;
+  }
+}
+
+inline int grid_for(int64_t n, int block, int maxb)
+{
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > maxb) g = maxb;
+  return (int)g;
+}
+
+template <int NB>
+void launch_fused_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
+                     const double* off, double* w_store, int64_t N, double* partial, double* PP, uint64_t seed,
+                     uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+{
+  constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
+  if (mode == blk::W_DRAW)
+    hipLaunchKernelGGL((k_sweep_fused<NB, blk::W_DRAW>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, n, beta, off,
+                       w_store, N, partial, seed, epoch, idx0, status);
+  else
+    hipLaunchKernelGGL((k_sweep_fused<NB, blk::W_EM>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, n, beta, off,
+                       w_store, N, partial, seed, epoch, idx0, status);
+  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(kBlock), 0, s, partial, plan.nblocks, PP);
+}
+
+}  // namespace
+
+namespace blk {
+
+SweepPlan make_plan(int64_t N, int P, int num_cus)
+{
+  SweepPlan p;
+  p.P = P;
+  if (P % 16 == 0 && P >= 16 && P <= 64) {
+    p.fused = 1;
+    p.nb = P / 16;
+    const int64_t ntiles = (N + 63) / 64;
+    int64_t nb = (ntiles + 3) / 4;
+    if (nb < 1) nb = 1;
+    if (nb > num_cus) nb = num_cus;       // one workgroup (4 waves, one per SIMD) per CU
+    p.nblocks = (int)nb;
+    p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 4 * 64;
+  } else {
+    p.fused = 0;
+    const int T = (P + 63) / 64;
+    p.ntile = T * (T + 1) / 2;
+    int64_t chunks = (N + 4095) / 4096;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 512) chunks = 512;
+    p.nblocks = (int)chunks;
+    p.partial_doubles = (size_t)p.nblocks * p.ntile * 4096;
+  }
+  return p;
+}
+
+void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
+                  double* w_store, double* w_scratch, int64_t N, double* partial, double* PPpart, uint64_t seed,
+                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+{
+  const int P = plan.P;
+  if (plan.fused) {
+    switch (plan.nb) {
+      case 1: launch_fused_nb<1>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      case 2: launch_fused_nb<2>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      case 3: launch_fused_nb<3>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      default: launch_fused_nb<4>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+    }
+    return;
+  }
+  double* w = w_store ? w_store : w_scratch;
+  const int g = grid_for(N, kBlock, 256 * 8);
+  if (mode == W_DRAW)
+    hipLaunchKernelGGL((k_psi_omega<W_DRAW>), dim3(g), dim3(kBlock), sizeof(double) * P, s, tX, n, beta, off, w, N, P,
+                       seed, epoch, idx0, status);
+  else
+    hipLaunchKernelGGL((k_psi_omega<W_EM>), dim3(g), dim3(kBlock), sizeof(double) * P, s, tX, n, beta, off, w, N, P,
+                       seed, epoch, idx0, status);
+  const int T = (P + 63) / 64;
+  int64_t rpc = (N + plan.nblocks - 1) / plan.nblocks;
+  rpc = (rpc + kRows - 1) / kRows * kRows;
+  if (rpc < kRows) rpc = kRows;
+  hipLaunchKernelGGL(k_xwx_tiles, dim3(plan.nblocks, plan.ntile), dim3(kBlock), 0, s, tX, w, N, P, T, rpc, partial);
+  hipLaunchKernelGGL(k_reduce_tiles, dim3(grid_for((int64_t)plan.ntile * 4096, kBlock, 1024)), dim3(kBlock), 0, s,
+                     partial, plan.nblocks, P, T, PPpart);
+}
+
+static int colsum_blocks(int64_t N)
+{
+  int64_t b = (N + 2047) / 2048;
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+size_t colsum_ws_doubles(int64_t N, int P) { return (size_t)colsum_blocks(N) * P; }
+
+void launch_colsum(const double* tX, const double* y, const double* n, const double* w, const double* c, int64_t N,
+                   int P, double* ws, double* out, hipStream_t s)
+{
+  const int nb = colsum_blocks(N);
+  const int64_t rpb = (N + nb - 1) / nb;
+  const int cols = P < kBlock ? P : kBlock;
+  const int rowlanes = kBlock / cols;
+  hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(kBlock), sizeof(double) * rowlanes * P, s, tX, y, n, w, c, N, P,
+                     rpb > 0 ? rpb : 1, ws);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3(grid_for(P, kBlock, 64)), dim3(kBlock), 0, s, ws, nb, P, out);
+}
+
+void launch_xbeta(const double* tX, const double* beta, int64_t N, int P, double* out, hipStream_t s)
+{
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_xbeta, dim3(grid_for(N, kBlock, 256 * 8)), dim3(kBlock), sizeof(double) * P, s, tX, beta, N, P,
+                     out);
+}
+
+void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, hipStream_t s)
+{
+  if (N <= 0) return;
+  hipLaunchKernelGGL(k_mlogit_offset, dim3(grid_for(N, kBlock, 256 * 8)), dim3(kBlock), 0, s, XB, N, J, j, c_out);
+}
+
+size_t beta_work_doubles(int P) { return 2 * (size_t)P * P + 6 * (size_t)P + 64; }
+
+void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
+{
+  size_t lds = 0;
+  if (mode == B_CONSTRAINED) {
+    const size_t pp = (size_t)a.P * a.P * 8;
+    lds = (pp <= 128 * 1024 ? pp : 0) + 3 * (size_t)a.P * 8 + 64;
+    if (pp > 128 * 1024) lds = 0;
+  }
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), lds, s, a, mode);
+}
+
+void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_maxabsdiff, dim3(1), dim3(kBlock), 0, s, a, b, P, out);
+}
+void launch_vec_add(double* dst, const double* a, const double* b, int P, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_vec_add, dim3(1), dim3(kBlock), 0, s, dst, a, b, P);
+}
+void launch_matvec(double* dst, const double* M, const double* v, int P, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_matvec, dim3(1), dim3(kBlock), 0, s, dst, M, v, P);
+}
+
+}  // namespace blk

@@ -1,0 +1,389 @@
+// kernels_pg.hip -- the rpg_* family on MI355X: one PG(b_i, z_i) draw per lane,
+// each observation on its own Philox stream.  Replaces the serial loops of
+// Code/C/LogitWrapper.cpp:39-167.  gfx950 only.
+#include "bl_host.hpp"
+#include "bl_pg_hybrid.hpp"
+
+namespace {
+
+using namespace bl;
+
+constexpr int kBlock = 256;        // 4 wavefronts
+constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond
+
+// ---------------------------------------------------------------- rpg_devroye
+// v1: one observation per lane per grid-stride step, per-lane rejection loops.
+__global__ __launch_bounds__(kBlock) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
+                                                        int nscalar, const double* __restrict__ z, int64_t num,
+                                                        uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                        int* __restrict__ status)
+{
+  int st = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    const int n = nvec ? nvec[i] : nscalar;
+    double out = 0.0;
+    if (n != 0) {
+      Stream r;
+      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
+      out = pg_draw_devroye(n, z[i], r, st);
+    }
+    x[i] = out;
+  }
+  if (st) atomicOr(status, st);
+}
+
+// ------------------------------------------------ rpg_alt / rpg_sp / rpg_gamma
+__global__ __launch_bounds__(kBlock) void k_rpg_alt(double* __restrict__ x, const double* __restrict__ h,
+                                                    const double* __restrict__ z, int64_t num, uint64_t seed,
+                                                    uint32_t epoch, uint64_t idx0, int* __restrict__ status)
+{
+  int st = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    double out = 0.0;
+    if (h[i] != 0.0) {
+      Stream r;
+      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
+      out = alt_draw(h[i], z[i], r, st);
+    }
+    x[i] = out;
+  }
+  if (st) atomicOr(status, st);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rpg_sp(double* __restrict__ x, const double* __restrict__ h,
+                                                   const double* __restrict__ z, int64_t num,
+                                                   int* __restrict__ iter, uint64_t seed, uint32_t epoch,
+                                                   uint64_t idx0, int* __restrict__ status)
+{
+  int st = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    if (h[i] != 0.0) {
+      Stream r;
+      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
+      double out;
+      const int it = sp_draw(out, h[i], z[i], r, 200, st);
+      x[i] = out;
+      if (iter) iter[i] = it;
+    } else {
+      x[i] = 0.0;   // iter[i] untouched, LogitWrapper.cpp:118-121
+    }
+  }
+  if (st) atomicOr(status, st);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rpg_gamma(double* __restrict__ x, const double* __restrict__ h,
+                                                      const double* __restrict__ z, int64_t num, int trunc,
+                                                      uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    double out = 0.0;
+    if (h[i] != 0.0) {
+      Stream r;
+      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
+      out = pg_draw_sum_of_gammas(h[i], z[i], trunc, r);
+    }
+    x[i] = out;
+  }
+}
+
+// ----------------------------------------------------------------- rpg_hybrid
+// The five branches of LogitWrapper.cpp:142-161 have very different register
+// footprints and trip counts; a lane-per-observation kernel that switches per
+// lane would keep the union of all branches' registers live and serialise every
+// branch in every wavefront.  The launch is therefore split by class: each pass
+// is a separate kernel instantiation that contains the code of ONE class only
+// and skips observations of the other classes.  Streams are per observation, so
+// the result is identical to the unsplit loop.
+template <int CLS>
+__global__ __launch_bounds__(kBlock) void k_rpg_hybrid_class(double* __restrict__ x,
+                                                             const double* __restrict__ h,
+                                                             const double* __restrict__ z, int64_t num,
+                                                             uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                             int* __restrict__ status)
+{
+  int st = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    const double b = h[i];
+    if (pg_class(b) != CLS) continue;
+    double out = 0.0;
+    if (CLS != CLS_ZERO) {
+      Stream r;
+      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
+      out = pg_hybrid_class(CLS, b, z[i], r, st);
+    }
+    x[i] = out;
+  }
+  if (st) atomicOr(status, st);
+}
+
+// ------------------------------------------------------------ synthetic data
+__global__ __launch_bounds__(kBlock) void k_fill_unif(double* __restrict__ out, int64_t num, double lo, double hi,
+                                                      uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    Stream r;
+    r.init(seed, idx0 + (uint64_t)i, DOM_DATA, epoch);
+    out[i] = r.flat(lo, hi);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_norm(double* __restrict__ out, int64_t num, double mean, double sd,
+                                                      uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    Stream r;
+    r.init(seed, idx0 + (uint64_t)i, DOM_DATA, epoch);
+    out[i] = r.norm(mean, sd);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_shape(double* __restrict__ out, int64_t num, int kmax,
+                                                       uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
+    const uint64_t idx = idx0 + (uint64_t)i;
+    const U4 o = philox4x32_10((uint32_t)idx, ((uint32_t)(idx >> 32) & 0x00FFFFFFu) | (DOM_DATA << 24), epoch, 0,
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[i] = 1.0 + (double)(o.x % (uint32_t)kmax);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_logit_y(double* __restrict__ y, const double* __restrict__ tX,
+                                                         const double* __restrict__ beta, int64_t N, int P,
+                                                         uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+    const double* xr = tX + (size_t)i * P;
+    double s = 0.0;
+    for (int j = 0; j < P; ++j) s += xr[j] * beta[j];
+    Stream r;
+    r.init(seed, idx0 + (uint64_t)i, DOM_DATA, epoch);
+    y[i] = r.unif() < 1.0 / (1.0 + exp(-s)) ? 1.0 : 0.0;
+  }
+}
+
+int check_args(const void* a, const void* b, int64_t num)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  if (num < 0 || (num > 0 && (!a || !b))) {
+    blh::set_error("null pointer or negative length");
+    return BL_ERR_ARG;
+  }
+  return BL_OK;
+}
+
+}  // namespace
+
+// =============================================================== Part 2 (device)
+extern "C" {
+
+int bl_rpg_devroye_dev(double* x, const int* n_vec, int n_scalar, const double* z, int64_t num, uint64_t seed,
+                       uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rpg_devroye, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, n_vec,
+                     n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_rpg_alt_dev(double* x, const double* h, const double* z, int64_t num, uint64_t seed, uint32_t epoch,
+                   uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rpg_alt, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, h, z, num, seed,
+                     epoch, idx0, blh::status_word(s));
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_rpg_sp_dev(double* x, const double* h, const double* z, int64_t num, int* iter, uint64_t seed,
+                  uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rpg_sp, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, h, z, num, iter,
+                     seed, epoch, idx0, blh::status_word(s));
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_rpg_gamma_dev(double* x, const double* h, const double* z, int64_t num, int trunc, uint64_t seed,
+                     uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rpg_gamma, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, h, z, num,
+                     trunc, seed, epoch, idx0);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_rpg_hybrid_dev(double* x, const double* h, const double* z, int64_t num, uint64_t seed, uint32_t epoch,
+                      uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(blh::grid_for(num, kBlock, kMaxBlocks)), b(kBlock);
+  int* st = blh::status_word(s);
+  // Every class pass is launched; a pass whose class is absent costs one read of h.
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_ZERO>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_ALT>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_SP>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_fill_unif_dev(double* out, int64_t num, double lo, double hi, uint64_t seed, uint32_t epoch, uint64_t idx0,
+                     void* stream)
+{
+  if (int rc = check_args(out, out, num)) return rc;
+  if (num == 0) return BL_OK;
+  hipLaunchKernelGGL(k_fill_unif, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, (hipStream_t)stream,
+                     out, num, lo, hi, seed, epoch, idx0);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_fill_norm_dev(double* out, int64_t num, double mean, double sd, uint64_t seed, uint32_t epoch, uint64_t idx0,
+                     void* stream)
+{
+  if (int rc = check_args(out, out, num)) return rc;
+  if (num == 0) return BL_OK;
+  hipLaunchKernelGGL(k_fill_norm, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, (hipStream_t)stream,
+                     out, num, mean, sd, seed, epoch, idx0);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_fill_shape_dev(double* out, int64_t num, int kmax, uint64_t seed, uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(out, out, num)) return rc;
+  if (kmax < 1) { blh::set_error("kmax < 1"); return BL_ERR_ARG; }
+  if (num == 0) return BL_OK;
+  hipLaunchKernelGGL(k_fill_shape, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, (hipStream_t)stream,
+                     out, num, kmax, seed, epoch, idx0);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_fill_logit_y_dev(double* y, const double* tX, const double* beta, int64_t N, int P, uint64_t seed,
+                        uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(y, tX, N)) return rc;
+  if (!beta || P < 1) { blh::set_error("beta null or P < 1"); return BL_ERR_ARG; }
+  if (N == 0) return BL_OK;
+  hipLaunchKernelGGL(k_fill_logit_y, dim3(blh::grid_for(N, kBlock, kMaxBlocks)), dim3(kBlock), 0, (hipStream_t)stream,
+                     y, tX, beta, N, P, seed, epoch, idx0);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+}  // extern "C"
+
+// ================================================== Part 1 (.C boundary, host)
+namespace {
+
+template <class Launch>
+void run_host_rpg(const char* name, double* x, const double* hd, const int* hi, const double* z, int num, int* iter,
+                  Launch launch)
+{
+  if (!blh::ensure_device()) return;
+  if (num <= 0) return;
+  blh::DevBuf<double> dx, dh, dz;
+  blh::DevBuf<int> dn, dit;
+  hipError_t e = dx.alloc(num);
+  if (e == hipSuccess) e = dz.alloc(num);
+  if (e == hipSuccess && hd) e = dh.alloc(num);
+  if (e == hipSuccess && hi) e = dn.alloc(num);
+  if (e == hipSuccess && iter) e = dit.alloc(num);
+  if (e == hipSuccess) e = dz.upload(z);
+  if (e == hipSuccess && hd) e = dh.upload(hd);
+  if (e == hipSuccess && hi) e = dn.upload(hi);
+  if (e == hipSuccess && iter) e = dit.upload(iter);   // untouched entries keep the caller's value
+  if (e != hipSuccess) {
+    blh::set_error(std::string(name) + ": " + hipGetErrorString(e));
+    return;
+  }
+  const int rc = launch(dx.p, dh.p, dn.p, dz.p, dit.p);
+  if (rc == BL_OK) blh::collect_status(nullptr);   // prints a message on sampler flags, like the reference's Rprintf
+  e = dx.download(x);
+  if (e == hipSuccess && iter) e = dit.download(iter);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) blh::set_error(std::string(name) + ": " + hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" {
+
+void rpg_devroye(double* x, int* n, double* z, int* num)
+{
+  const uint64_t seed = blh::global_seed();
+  const uint32_t ep = blh::next_epoch();
+  run_host_rpg("rpg_devroye", x, nullptr, n, z, *num, nullptr,
+               [&](double* dx, double*, int* dn, double* dz, int*) {
+                 return bl_rpg_devroye_dev(dx, dn, 1, dz, *num, seed, ep, 0, nullptr);
+               });
+}
+
+void rpg_alt(double* x, double* h, double* z, int* num)
+{
+  const uint64_t seed = blh::global_seed();
+  const uint32_t ep = blh::next_epoch();
+  run_host_rpg("rpg_alt", x, h, nullptr, z, *num, nullptr, [&](double* dx, double* dh, int*, double* dz, int*) {
+    return bl_rpg_alt_dev(dx, dh, dz, *num, seed, ep, 0, nullptr);
+  });
+}
+
+void rpg_sp(double* x, double* h, double* z, int* num, int* iter)
+{
+  const uint64_t seed = blh::global_seed();
+  const uint32_t ep = blh::next_epoch();
+  run_host_rpg("rpg_sp", x, h, nullptr, z, *num, iter, [&](double* dx, double* dh, int*, double* dz, int* dit) {
+    return bl_rpg_sp_dev(dx, dh, dz, *num, dit, seed, ep, 0, nullptr);
+  });
+}
+
+void rpg_gamma(double* x, double* n, double* z, int* num, int* trunc)
+{
+  const uint64_t seed = blh::global_seed();
+  const uint32_t ep = blh::next_epoch();
+  run_host_rpg("rpg_gamma", x, n, nullptr, z, *num, nullptr, [&](double* dx, double* dh, int*, double* dz, int*) {
+    return bl_rpg_gamma_dev(dx, dh, dz, *num, *trunc, seed, ep, 0, nullptr);
+  });
+}
+
+void rpg_hybrid(double* x, double* h, double* z, int* num)
+{
+  const uint64_t seed = blh::global_seed();
+  const uint32_t ep = blh::next_epoch();
+  run_host_rpg("rpg_hybrid", x, h, nullptr, z, *num, nullptr, [&](double* dx, double* dh, int*, double* dz, int*) {
+    return bl_rpg_hybrid_dev(dx, dh, dz, *num, seed, ep, 0, nullptr);
+  });
+}
+
+}  // extern "C"

@@ -41,7 +41,8 @@ void bl_rng_init(bl_rng *r, uint64_t seed, uint64_t idx, uint32_t domain, uint32
   r->nunif = 0;
 }
 
-/* U(0,1), 53 bits, never 0 or 1.  r.unif() of the reference. */
+/* U(0,1) on the 52-bit grid (m + 1/2) 2^-52: exact in binary64, never 0 or 1.
+ * r.unif() of the reference. */
 double bl_unif(bl_rng *r)
 {
   if (r->pos >= 2) {
@@ -52,8 +53,8 @@ double bl_unif(bl_rng *r)
   uint32_t a = r->buf[2 * r->pos], b = r->buf[2 * r->pos + 1];
   r->pos += 1;
   r->nunif += 1;
-  uint64_t m = (((uint64_t)a << 32) | b) >> 11;
-  return ((double)m + 0.5) * 0x1.0p-53;
+  uint64_t m = (((uint64_t)a << 32) | b) >> 12;
+  return ((double)m + 0.5) * 0x1.0p-52;
 }
 
 /* r.expon_rate(rate): rexp in Code/R/PG.R:86-90,152. */
