@@ -184,7 +184,9 @@ __device__ inline double tnorm(Stream& r, double lo, double hi)
   if (lo_inf && hi_inf) return r.norm(0.0, 1.0);
   if (hi_inf) return tail_norm(r, lo);
   if (lo_inf) return -tail_norm(r, -hi);
-  if (!(lo < hi)) return lo;
+  // degenerate interval (chain start on the constraint boundary): coarse width test so
+  // rounding noise in the bounds cannot change the number of uniforms consumed
+  if (!(hi - lo > 1e-12)) return lo;
   if (lo <= 0.0 && hi >= 0.0) {
     if (hi - lo > 2.5066282746310002) {
       double x = r.norm(0.0, 1.0);

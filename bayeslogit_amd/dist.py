@@ -1,0 +1,67 @@
+"""Observation-sharded logistic Gibbs over torch.distributed (RCCL on MI355X).
+
+One process per GPU.  Rank k holds rows [idx0_k, idx0_k + N_k) of X.  Per sweep
+(reference loop Code/C/Logit.hpp:426-450):
+
+    shard.sweep_local(s)        psi, omega, partial PP_k = X_k' Omega_k X_k   (one pass over X_k)
+    all_reduce(shard.pp())      the ONLY per-sweep exchange: P*P float64 over xGMI
+    shard.draw_beta(s, c)       PP += P0, Cholesky, beta draw -- redundantly on every rank from
+                                the same (seed, sweep) Philox stream, so beta needs no broadcast
+
+X'kappa (constant over the chain, Logit.hpp:174-183) is all-reduced once at setup.
+omega_i is keyed by the GLOBAL observation index, so the draws do not depend on
+how many ranks share the rows.
+
+`shard` is any object with the GibbsShard interface (bayeslogit_amd.device.GibbsShard
+is the HIP one); the driver itself only sequences calls and collectives, which is
+what the world_size-2 gloo tests exercise on CPU with a stand-in shard.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(N, rank, world):
+    """Contiguous rows of rank `rank`: sizes differ by at most one, order preserved."""
+    base, rem = divmod(N, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DistGibbs:
+    def __init__(self, shard, group=None):
+        self.shard = shard
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _all_reduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def setup(self, m0, P0, beta0=None):
+        s = self.shard
+        s.set_prior(m0, P0)
+        s.set_bp_local()
+        self._all_reduce(s.bp())
+        s.finish_bp()
+        if beta0 is not None:
+            s.set_beta(beta0)
+
+    def sweep(self, sweep, constrain=1, w_out=None):
+        s = self.shard
+        s.sweep_local(sweep, w_out)
+        self._all_reduce(s.pp())
+        s.draw_beta(sweep, constrain)
+
+    def run(self, samp, burn, constrain=1):
+        """burn + samp sweeps; returns beta history (samp, P) as a CPU tensor."""
+        s = self.shard
+        hist = []
+        sweep = 0
+        for _ in range(burn):
+            self.sweep(sweep, constrain)
+            sweep += 1
+        for _ in range(samp):
+            self.sweep(sweep, constrain)
+            hist.append(s.beta().clone())
+            sweep += 1
+        return torch.stack(hist).cpu()

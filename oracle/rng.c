@@ -177,7 +177,11 @@ double bl_tnorm(bl_rng *r, double lo, double hi)
   if (lo_inf && hi_inf) return bl_norm(r, 0.0, 1.0);
   if (hi_inf) return tail_norm(r, lo);
   if (lo_inf) return -tail_norm(r, -hi);
-  if (!(lo < hi)) return lo;            /* degenerate interval */
+  /* Degenerate interval (the chain starts on the constraint boundary, beta = 0,
+   * where cmin == cmax up to rounding): no room to move and no uniforms consumed.
+   * The width test is deliberately coarse so that rounding noise in the bounds
+   * cannot change how many uniforms a call consumes. */
+  if (!(hi - lo > 1e-12)) return lo;
   /* both finite */
   if (lo <= 0.0 && hi >= 0.0) {
     if (hi - lo > 2.5066282746310002) { /* sqrt(2 pi) */

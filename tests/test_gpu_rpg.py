@@ -1,0 +1,229 @@
+"""GPU parity of the rpg_* family, through the C ABI, against the oracle on the same Philox
+coordinates.  Tolerance: the GPU and the oracle run the same fp64 algorithm on the same uniforms but
+with different libm implementations (ocml vs glibc, <= 1-2 ulp each) and FMA contraction, so draws
+agree to RTOL = 1e-10 relative; an accept/reject decision that lands within an ulp of its threshold can
+flip (probability ~1e-15 per test), which MAX_FLIP_FRAC tolerates."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy import stats
+
+import pgmath
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+MAX_FLIP_FRAC = 1e-5
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def agree(got, ref, rtol=RTOL):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+    bad = np.sum(~((rel <= rtol) | (got == ref)))
+    assert bad <= MAX_FLIP_FRAC * got.size, (bad, rel.max())
+
+
+def dev_t(a, gpu, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=gpu)
+
+
+def test_dot_C_entry_points_match_oracle(gpu, oracle):
+    """The ten-symbol boundary with host buffers, exactly as R's .C calls it (LogitWrapper.R:29..118)."""
+    import bayeslogit_amd as bl
+    rng = np.random.default_rng(1)
+    num = 3000
+    z = rng.normal(0, 2, num)
+    bl.set_seed(1234)
+    x = bl.rpg_devroye(num, n=[1, 2, 3, 0], z=z)                     # epoch 0
+    agree(x, oracle.rpg_devroye(num, np.resize([1, 2, 3, 0], num), z, 1234, 0))
+    x = bl.rpg_alt(num, h=[1.0, 2.5, 4.0, 7.7, 12.0], z=z)           # epoch 1
+    agree(x, oracle.rpg_alt(num, np.resize([1.0, 2.5, 4.0, 7.7, 12.0], num), z, 1234, 1))
+    r = bl.rpg_sp(num, h=[14.0, 30.0, 170.0], z=z, track_iter=True)  # epoch 2
+    xo, ito = oracle.rpg_sp(num, np.resize([14.0, 30.0, 170.0], num), z, 1234, 2)
+    agree(r["samp"], xo)
+    assert np.mean(r["iter"] == ito) > 1 - MAX_FLIP_FRAC
+    x = bl.rpg_gamma(400, h=[0.3, 1.0, 2.2], z=z[:400], trunc=50)    # epoch 3
+    agree(x, oracle.rpg_gamma(400, np.resize([0.3, 1.0, 2.2], 400), z[:400], 1234, 50, 3), 1e-9)
+    h = np.concatenate([rng.integers(1, 51, num - 600).astype(float), rng.uniform(0.05, 0.99, 100),
+                        rng.uniform(1, 13, 200), rng.uniform(13, 170, 200), rng.uniform(170, 500, 100)])
+    x = bl.rpg(num, h=h, z=z)                                        # epoch 4
+    agree(x, oracle.rpg_hybrid(num, h, z, 1234, 4), 1e-9)
+    assert bl._lib.lib().bl_get_epoch() == 5
+    # same seed again -> same sequence of calls reproduces (R: set.seed)
+    bl.set_seed(1234)
+    a = bl.rpg(100, 1.0, 0.5)
+    bl.set_seed(1234)
+    assert np.array_equal(a, bl.rpg(100, 1.0, 0.5))
+
+
+def test_C1_plumbing(gpu):
+    """BASELINE config C1 through the boundary: rpg(num=1e3, h=1, z=0), KS vs exact PG(1,0)."""
+    import bayeslogit_amd as bl
+    bl.set_seed(2024)
+    x = bl.rpg(1000, 1, 0.0)
+    assert x.shape == (1000,)
+    assert stats.kstest(x, lambda w: pgmath.pg1_cdf(w, 0.0)).pvalue > 0.01
+    assert abs(x.mean() - 0.25) < 4 * np.sqrt(1 / 24 / 1000)
+
+
+@pytest.mark.parametrize("case", ["devroye", "alt", "sp", "hybrid", "thresholds"])
+def test_device_entry_points_match_oracle(gpu, oracle, case):
+    from bayeslogit_amd import device as D
+    rng = np.random.default_rng(7)
+    n = 60000
+    z = np.concatenate([rng.uniform(0, 4, n // 2), rng.normal(0, 3, n - n // 2 - 4), [0.0, -0.0, 60.0, 1e-9]])
+    zt = dev_t(z, gpu)
+    if case == "devroye":
+        nv = rng.integers(0, 5, n).astype(np.int32)
+        x = D.rpg_devroye(zt, dev_t(nv, gpu, torch.int32), seed=5, epoch=2, idx0=2 ** 40)
+        D.sync_status()
+        agree(x.cpu().numpy(), oracle.rpg_devroye(n, nv, z, 5, 2, 2 ** 40))
+    elif case == "alt":
+        h = rng.uniform(1, 13, n)
+        h[:100] = np.repeat([1.0, 4.0, 4.000001, 5.0, 8.0, 9.0, 12.999, 3.99, 2.0, 1.009], 10)
+        x = D.rpg_alt(dev_t(h, gpu), zt, seed=6)
+        D.sync_status()
+        agree(x.cpu().numpy(), oracle.rpg_alt(n, h, z, 6))
+    elif case == "sp":
+        h = rng.uniform(13, 170, n)
+        h[:6] = [13.0001, 14.0, 50.0, 100.0, 169.9, 170.0]
+        it = torch.full((n,), -1, dtype=torch.int32, device=gpu)
+        x = D.rpg_sp(dev_t(h, gpu), zt, seed=7, iters=it)
+        D.sync_status()
+        xo, ito = oracle.rpg_sp(n, h, z, 7)
+        agree(x.cpu().numpy(), xo)
+        assert np.mean(it.cpu().numpy() == ito) > 1 - MAX_FLIP_FRAC
+    elif case == "hybrid":
+        h = 1.0 + rng.integers(0, 50, n)
+        x = D.rpg_hybrid(dev_t(h, gpu), zt, seed=8, epoch=1, idx0=17)
+        D.sync_status()
+        agree(x.cpu().numpy(), oracle.rpg_hybrid(n, h, z, 8, 1, 17), 1e-9)
+    else:
+        # every branch boundary of LogitWrapper.cpp:142-161
+        hb = np.array([0.0, -1.0, 1e-3, 0.999, 1.0, 1.0000001, 2.0, 2.5, 13.0, 13.0000001, 170.0, 170.0000001, 1e4])
+        h = np.resize(hb, 1300)
+        zz = np.resize(z, 1300)
+        x = D.rpg_hybrid(dev_t(h, gpu), dev_t(zz, gpu), seed=9)
+        D.sync_status()
+        xo = oracle.rpg_hybrid(1300, h, zz, 9)
+        agree(x.cpu().numpy(), xo, 1e-9)
+        assert np.all(x.cpu().numpy()[h <= 0] == 0)
+
+
+def test_golden_vectors_on_gpu(gpu):
+    from bayeslogit_amd import device as D
+    g = json.load(open(os.path.join(HERE, "golden", "pg_golden_v1.json")))
+    for d in g["hybrid_draws"]:
+        k = len(d["x"])
+        h = torch.full((k,), d["b"], dtype=torch.float64, device=gpu)
+        z = torch.full((k,), d["z"], dtype=torch.float64, device=gpu)
+        x = D.rpg_hybrid(h, z, seed=d["seed"], epoch=d["epoch"], idx0=d["idx0"])
+        D.sync_status()
+        agree(x.cpu().numpy(), np.array(d["x"]), 1e-9)
+    d = g["devroye_n"]
+    x = D.rpg_devroye(dev_t(d["z"], gpu), dev_t(d["n"], gpu, torch.int32), seed=d["seed"])
+    D.sync_status()
+    agree(x.cpu().numpy(), np.array(d["x"]))
+    d = g["sp_iter"]
+    it = torch.zeros(6, dtype=torch.int32, device=gpu)
+    x = D.rpg_sp(dev_t(d["h"], gpu), torch.full((6,), d["z"], dtype=torch.float64, device=gpu), seed=d["seed"], iters=it)
+    D.sync_status()
+    agree(x.cpu().numpy(), np.array(d["x"]))
+    assert it.cpu().tolist() == d["iter"]
+
+
+def test_edge_cases(gpu, oracle):
+    import bayeslogit_amd as bl
+    from bayeslogit_amd import device as D
+    # empty input
+    e = torch.empty(0, dtype=torch.float64, device=gpu)
+    assert D.rpg_devroye(e, 1, seed=1).numel() == 0
+    assert D.rpg_hybrid(e, e, seed=1).numel() == 0
+    assert bl.rpg_devroye(0).shape == (0,)
+    # single element, ragged (not a multiple of 64 / 256) lengths
+    for n in (1, 63, 65, 257, 1000):
+        z = np.linspace(-3, 3, n)
+        x = D.rpg_devroye(dev_t(z, gpu), 1, seed=3, idx0=5)
+        agree(x.cpu().numpy(), oracle.rpg_devroye(n, 1, z, 3, 0, 5))
+    # n < 1 is clamped to 1 and flagged (NTHROW build, PolyaGamma.cpp:128-135)
+    x = D.rpg_devroye(dev_t([1.0, 1.0], gpu), dev_t([-2, 1], gpu, torch.int32), seed=4)
+    with pytest.raises(bl.BayesLogitError):
+        D.sync_status()
+    assert bl._lib.lib().bl_last_sampler_flags() & 2
+    agree(x.cpu().numpy(), oracle.rpg_devroye(2, [-2, 1], [1.0, 1.0], 4))
+    D.sync_status()   # flags were cleared by the failed sync
+
+
+def test_determinism_and_shard_invariance(gpu):
+    """Fixed counter seed => identical output; an index range split over ranks gives the same draws."""
+    from bayeslogit_amd import device as D
+    n = 300001
+    z = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_unif(z, 0.0, 4.0, 20240001)
+    a = D.rpg_devroye(z, 1, seed=77, epoch=5)
+    b = D.rpg_devroye(z, 1, seed=77, epoch=5)
+    assert torch.equal(a, b)
+    cut = 123457
+    lo = D.rpg_devroye(z[:cut].contiguous(), 1, seed=77, epoch=5, idx0=0)
+    hi = D.rpg_devroye(z[cut:].contiguous(), 1, seed=77, epoch=5, idx0=cut)
+    assert torch.equal(torch.cat([lo, hi]), a)
+    c = D.rpg_devroye(z, 1, seed=77, epoch=6)
+    assert not torch.equal(a, c)
+    h = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_shape(h, 50, 20240001, epoch=1)
+    assert int(h.min()) == 1 and int(h.max()) == 50
+    m1 = D.rpg_hybrid(h, z, seed=78)
+    m2 = torch.cat([D.rpg_hybrid(h[:cut].contiguous(), z[:cut].contiguous(), seed=78),
+                    D.rpg_hybrid(h[cut:].contiguous(), z[cut:].contiguous(), seed=78, idx0=cut)])
+    assert torch.equal(m1, m2)
+    D.sync_status()
+
+
+def test_full_size_C2_properties(gpu):
+    """BASELINE C2 at full size (1e8 draws): size-independent properties -- positivity, sample moments
+    against the closed forms E[PG(1,z)] = tanh(z/2)/(2z) (the reference tests' criterion) averaged over
+    z ~ U(0,4), KS of a z-slice against the exact CDF, and a checksum that is stable across two runs."""
+    from bayeslogit_amd import device as D
+    n = 100_000_000
+    z = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_unif(z, 0.0, 4.0, 20240001)
+    x = D.rpg_devroye(z, 1, seed=20240002)
+    D.sync_status()
+    assert bool((x > 0).all()) and bool(torch.isfinite(x).all())
+    m_expect = (torch.tanh(z / 2) / (2 * z)).mean().item()
+    v_expect = ((torch.sinh(z) - z) / (4 * z ** 3 * torch.cosh(z / 2) ** 2)).mean().item()
+    assert abs(x.mean().item() - m_expect) < 6 * np.sqrt(0.05 / n)
+    resid = x - torch.tanh(z / 2) / (2 * z)
+    assert abs((resid ** 2).mean().item() - v_expect) < 1e-5
+    sel = (z > 1.99) & (z < 2.01)
+    xs = x[sel][:200000].cpu().numpy()
+    assert stats.kstest(xs, lambda w: pgmath.pg1_cdf(w, 2.0)).pvalue > 1e-4
+    s1 = x.sum().item()
+    x2 = D.rpg_devroye(z, 1, seed=20240002)
+    assert torch.equal(x, x2) and x2.sum().item() == s1
+
+
+def test_full_size_C3_properties(gpu):
+    """BASELINE C3 (b in 1..50, z ~ N(0, sd^2 = 2)) at 2e7 draws: per-shape sample mean vs pg_m1."""
+    from bayeslogit_amd import device as D
+    n = 20_000_000
+    z = torch.empty(n, dtype=torch.float64, device=gpu)
+    h = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_norm(z, 0.0, 2 ** 0.5, 20240001)
+    D.fill_shape(h, 50, 20240001, epoch=1)
+    x = D.rpg_hybrid(h, z, seed=20240002)
+    D.sync_status()
+    assert bool((x > 0).all())
+    za = z.abs().clamp_min(1e-12)
+    mean_i = h * torch.tanh(za / 2) / (2 * za)
+    var_i = h * (torch.sinh(za) - za) / (4 * za ** 3 * torch.cosh(za / 2) ** 2)
+    for b in (1, 2, 3, 7, 13, 14, 30, 50):
+        m = h == b
+        k = int(m.sum())
+        err = (x[m] - mean_i[m]).mean().item()
+        assert abs(err) < 6 * np.sqrt(var_i[m].mean().item() / k), b
