@@ -159,61 +159,118 @@ __device__ inline double rtinvchi2(Stream& r, double scale, double trunc)
   return scale * X;
 }
 
-// X ~ N(0,1) | X >= a
-__device__ inline double tail_norm(Stream& r, double a)
+// Phi^{-1}(p), lower tail: Wichura (1988) AS 241 PPND16 (published algorithm).
+__device__ inline double qnorm(double p)
 {
-  if (a <= 0.0) {
-    double x = r.norm(0.0, 1.0);
-    for (int it = 0; it < 100000 && x < a; ++it) x = r.norm(0.0, 1.0);
-    return x;
+  const double q = p - 0.5;
+  double r, val;
+  if (fabs(q) <= 0.425) {
+    r = 0.180625 - q * q;
+    return q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
+                    + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                 + 133.14166789178437745) * r + 3.387132872796366608)
+           / (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
+                  + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
+               + 42.313330701600911252) * r + 1.0);
   }
-  const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
-  double x = a;
-  for (int it = 0; it < 100000; ++it) {
-    x = a + r.expon(alpha);
-    const double d = x - alpha;
-    if (log(r.unif()) <= -0.5 * d * d) break;
+  r = q < 0 ? p : 1.0 - p;
+  r = sqrt(-log(r));
+  if (r <= 5.0) {
+    r -= 1.6;
+    val = (((((((r * 7.7454501427834140764e-4 + 0.0227238449892691845833) * r + 0.24178072517745061177) * r
+               + 1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r
+            + 4.6303378461565452959) * r + 1.42343711074968357734)
+        / (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + 0.0151986665636164571966) * r
+               + 0.14810397642748007459) * r + 0.68976733498510000455) * r + 1.6763848301838038494) * r
+            + 2.05319162663775882187) * r + 1.0);
+  } else {
+    r -= 5.0;
+    val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + 0.0012426609473880784386) * r
+               + 0.026532189526576123093) * r + 0.29656057182850489123) * r + 1.7848265399172913358) * r
+            + 5.4637849111641143699) * r + 6.6579046435011037772)
+        / (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r
+               + 7.868691311456132591e-4) * r + 0.0148753612908506148525) * r + 0.13692988092273580531) * r
+            + 0.59983220655588793769) * r + 1.0);
   }
+  return q < 0.0 ? -val : val;
+}
+
+constexpr double kSqrtHalfR = 0.70710678118654752440084436210485;
+constexpr int kTnormUniforms = 9;
+
+// X ~ N(0,1) | a <= X <= b, 0 <= a < b (b may be +inf), by inversion of the upper tail.
+__device__ inline double tnorm_inv_right(double a, double b, double u)
+{
+  double x;
+  if (a > 37.0) {
+    const double w = isinf(b) ? 1.0 : -expm1(-a * (b - a));
+    x = a - log1p(-u * w) / a;
+  } else {
+    const double qa = 0.5 * erfc(a * kSqrtHalfR), qb = isinf(b) ? 0.0 : 0.5 * erfc(b * kSqrtHalfR);
+    x = -qnorm(qa - u * (qa - qb));
+  }
+  x = x < a ? a : x;
+  x = x > b ? b : x;
   return x;
 }
 
-// r.tnorm(lo, hi, 0, 1)
-__device__ inline double tnorm(Stream& r, double lo, double hi)
+// The four rejection attempts + inverse-CDF fallback of r.tnorm(lo, hi, 0, 1), given the
+// call's nine uniforms (U[2k], U[2k+1] = attempt k; U[8] = fallback).  A call always
+// owns exactly nine uniforms of its stream whatever the bounds, so the stream never
+// desynchronises on rounding noise in the bounds and a whole beta draw's random input
+// can be generated up front, off the serial coordinate loop.
+__device__ inline double tnorm_from_uniforms(const double* U, double lo, double hi)
 {
   const bool lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return r.norm(0.0, 1.0);
-  if (hi_inf) return tail_norm(r, lo);
-  if (lo_inf) return -tail_norm(r, -hi);
-  // degenerate interval (chain start on the constraint boundary): coarse width test so
-  // rounding noise in the bounds cannot change the number of uniforms consumed
-  if (!(hi - lo > 1e-12)) return lo;
+  if (lo_inf && hi_inf) return qnorm(U[8]);
+  if (!(hi - lo > 0.0)) return lo;
   if (lo <= 0.0 && hi >= 0.0) {
-    if (hi - lo > 2.5066282746310002) {
-      double x = r.norm(0.0, 1.0);
-      for (int it = 0; it < 100000 && (x < lo || x > hi); ++it) x = r.norm(0.0, 1.0);
-      return x;
+    const bool wide = hi - lo > 2.5066282746310002;
+    for (int k = 0; k < 4; ++k) {
+      const double ua = U[2 * k], ub = U[2 * k + 1];
+      if (wide) {
+        const double x = sqrt(-2.0 * log(ua)) * cospi(2.0 * ub);
+        if (x >= lo && x <= hi) return x;
+      } else {
+        const double x = lo + (hi - lo) * ua;
+        if (log(ub) <= -0.5 * x * x) return x;
+      }
     }
-    double x = lo;
-    for (int it = 0; it < 100000; ++it) {
-      x = r.flat(lo, hi);
-      if (log(r.unif()) <= -0.5 * x * x) break;
-    }
+    const double pl = lo_inf ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
+    const double ph = hi_inf ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
+    double x = qnorm(pl + U[8] * (ph - pl));
+    x = x < lo ? lo : x;
+    x = x > hi ? hi : x;
     return x;
   }
   const bool flip = hi < 0.0;
   const double a = flip ? -hi : lo, b = flip ? -lo : hi;
   const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
+  const bool tail = b - a > 1.0 / alpha;
   double x = a;
-  if (b - a > 1.0 / alpha) {
-    x = tail_norm(r, a);
-    for (int it = 0; it < 100000 && x > b; ++it) x = tail_norm(r, a);
-  } else {
-    for (int it = 0; it < 100000; ++it) {
-      x = r.flat(a, b);
-      if (log(r.unif()) <= 0.5 * (a * a - x * x)) break;
+  bool done = false;
+  for (int k = 0; k < 4 && !done; ++k) {
+    const double ua = U[2 * k], ub = U[2 * k + 1];
+    if (tail) {
+      x = a - log(ua) / alpha;
+      const double d = x - alpha;
+      done = x <= b && log(ub) <= -0.5 * d * d;
+    } else {
+      x = a + (b - a) * ua;
+      done = log(ub) <= 0.5 * (a * a - x * x);
     }
   }
+  if (!done) x = tnorm_inv_right(a, b, U[8]);
   return flip ? -x : x;
+}
+
+// r.tnorm(lo, hi, 0, 1)
+__device__ inline double tnorm(Stream& r, double lo, double hi)
+{
+  double U[kTnormUniforms];
+#pragma unroll
+  for (int k = 0; k < kTnormUniforms; ++k) U[k] = r.unif();
+  return tnorm_from_uniforms(U, lo, hi);
 }
 
 }  // namespace bl

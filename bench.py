@@ -243,7 +243,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline
     if rank == 0 and world == 1 and not a.no_cpu:
-        ncores = len(os.sched_getaffinity(0))
+        ncores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
         sample = 3_000_000 * max(1, min(ncores, 16))
         one, allc = cpu_baseline(sample, ncores)
         out["cpu_baseline"] = {

@@ -56,7 +56,8 @@ double bl_gamma_scale(bl_rng *r, double shape, double scale);
 double bl_igauss(bl_rng *r, double mu, double lambda);
 double bl_ltgamma(bl_rng *r, double shape, double rate, double trunc);
 double bl_rtinvchi2(bl_rng *r, double scale, double trunc);
-double bl_tnorm(bl_rng *r, double lo, double hi);
+double bl_tnorm(bl_rng *r, double lo, double hi);   /* always 9 uniforms */
+double bl_qnorm(double p);
 double bl_flat(bl_rng *r, double a, double b);
 
 /* ---- special functions of the absent RNG library ---- */

@@ -153,58 +153,118 @@ double bl_rtinvchi2(bl_rng *r, double scale, double trunc)
   return scale * X;
 }
 
-/* X ~ N(0,1) | X >= a.  Robert (1995) exponential rejection for a > 0. */
-static double tail_norm(bl_rng *r, double a)
+/* Phi^{-1}(p), lower tail: Wichura (1988) algorithm AS 241, routine PPND16
+ * (published algorithm, relative accuracy ~1e-16).  Used by the fallback of bl_tnorm. */
+double bl_qnorm(double p)
 {
-  if (a <= 0.0) {
-    double x;
-    do { x = bl_norm(r, 0.0, 1.0); } while (x < a);
-    return x;
+  double q = p - 0.5, r, val;
+  if (fabs(q) <= 0.425) {
+    r = 0.180625 - q * q;
+    return q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
+                    + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                 + 133.14166789178437745) * r + 3.387132872796366608)
+           / (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
+                  + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
+               + 42.313330701600911252) * r + 1.0);
   }
-  double alpha = 0.5 * (a + sqrt(a * a + 4.0));
-  for (;;) {
-    double x = a + bl_expon_rate(r, alpha);
-    double d = x - alpha;
-    if (log(bl_unif(r)) <= -0.5 * d * d) return x;
+  r = q < 0 ? p : 1.0 - p;
+  r = sqrt(-log(r));
+  if (r <= 5.0) {
+    r -= 1.6;
+    val = (((((((r * 7.7454501427834140764e-4 + 0.0227238449892691845833) * r + 0.24178072517745061177) * r
+               + 1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r
+            + 4.6303378461565452959) * r + 1.42343711074968357734)
+        / (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + 0.0151986665636164571966) * r
+               + 0.14810397642748007459) * r + 0.68976733498510000455) * r + 1.6763848301838038494) * r
+            + 2.05319162663775882187) * r + 1.0);
+  } else {
+    r -= 5.0;
+    val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + 0.0012426609473880784386) * r
+               + 0.026532189526576123093) * r + 0.29656057182850489123) * r + 1.7848265399172913358) * r
+            + 5.4637849111641143699) * r + 6.6579046435011037772)
+        / (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r
+               + 7.868691311456132591e-4) * r + 0.0148753612908506148525) * r + 0.13692988092273580531) * r
+            + 0.59983220655588793769) * r + 1.0);
   }
+  return q < 0.0 ? -val : val;
 }
 
-/* r.tnorm(lo, hi, 0, 1): standard normal restricted to (lo, hi), either bound
- * may be infinite.  Used by the constrained beta draw, Logit.hpp:393. */
+/* upper-tail probability Q(x) = 1 - Phi(x), relative accuracy in the tail */
+static double qtail(double x) { return 0.5 * erfc(x * M_SQRT1_2); }
+
+/* X ~ N(0,1) | a <= X <= b for 0 <= a < b (b may be +inf), by inversion of the upper
+ * tail: exact, one uniform.  Beyond a = 37 erfc underflows; there the tail is
+ * exponential to within 1/a^2 and is inverted in closed form. */
+static double tnorm_inv_right(double a, double b, double u)
+{
+  double x;
+  if (a > 37.0) {
+    double w = isinf(b) ? 1.0 : -expm1(-a * (b - a));
+    x = a - log1p(-u * w) / a;
+  } else {
+    double qa = qtail(a), qb = isinf(b) ? 0.0 : qtail(b);
+    double p = qa - u * (qa - qb);
+    x = -bl_qnorm(p);
+  }
+  if (x < a) x = a;
+  if (x > b) x = b;
+  return x;
+}
+
+/* r.tnorm(lo, hi, 0, 1): standard normal restricted to (lo, hi), either bound may be
+ * infinite.  Used by the constrained beta draw, Logit.hpp:393.  The reference's own
+ * algorithm lives in the absent RNG library; this one is ours, designed so that a
+ * call ALWAYS consumes exactly BL_TNORM_UNIFORMS = 9 uniforms whatever the bounds:
+ * four rejection attempts (two uniforms each: Robert 1995 exponential-tail /
+ * uniform / plain-normal proposals) and, if none accepts, one exact inverse-CDF
+ * draw from the ninth.  Fixed consumption keeps the stream aligned even when the
+ * bounds are rounding noise (chain sitting on the constraint boundary), so results
+ * depend continuously on the bounds; it also lets a GPU pre-generate every random
+ * input of a beta draw off the serial path. */
 double bl_tnorm(bl_rng *r, double lo, double hi)
 {
+  double U[9];
+  for (int k = 0; k < 9; ++k) U[k] = bl_unif(r);
   int lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return bl_norm(r, 0.0, 1.0);
-  if (hi_inf) return tail_norm(r, lo);
-  if (lo_inf) return -tail_norm(r, -hi);
-  /* Degenerate interval (the chain starts on the constraint boundary, beta = 0,
-   * where cmin == cmax up to rounding): no room to move and no uniforms consumed.
-   * The width test is deliberately coarse so that rounding noise in the bounds
-   * cannot change how many uniforms a call consumes. */
-  if (!(hi - lo > 1e-12)) return lo;
-  /* both finite */
+  if (lo_inf && hi_inf) return bl_qnorm(U[8]);
+  if (!(hi - lo > 0.0)) return lo;                      /* empty / degenerate / NaN */
   if (lo <= 0.0 && hi >= 0.0) {
-    if (hi - lo > 2.5066282746310002) { /* sqrt(2 pi) */
-      double x;
-      do { x = bl_norm(r, 0.0, 1.0); } while (x < lo || x > hi);
-      return x;
+    /* interval contains the mode */
+    int wide = hi - lo > 2.5066282746310002;            /* sqrt(2 pi); true for infinite bounds */
+    for (int k = 0; k < 4; ++k) {
+      double ua = U[2 * k], ub = U[2 * k + 1];
+      if (wide) {
+        double x = sqrt(-2.0 * log(ua)) * cos(2.0 * BL_PI * ub);
+        if (x >= lo && x <= hi) return x;
+      } else {
+        double x = lo + (hi - lo) * ua;
+        if (log(ub) <= -0.5 * x * x) return x;
+      }
     }
-    for (;;) {
-      double x = bl_flat(r, lo, hi);
-      if (log(bl_unif(r)) <= -0.5 * x * x) return x;
-    }
+    double pl = lo_inf ? 0.0 : 0.5 * erfc(-lo * M_SQRT1_2);
+    double ph = hi_inf ? 1.0 : 0.5 * erfc(-hi * M_SQRT1_2);
+    double x = bl_qnorm(pl + U[8] * (ph - pl));
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
   }
   /* interval on one side of zero: work on the positive side */
   int flip = hi < 0.0;
-  double a = flip ? -hi : lo, b = flip ? -lo : hi, x;
+  double a = flip ? -hi : lo, b = flip ? -lo : hi, x = a;
   double alpha = 0.5 * (a + sqrt(a * a + 4.0));
-  if (b - a > 1.0 / alpha) {
-    do { x = tail_norm(r, a); } while (x > b);
-  } else {
-    for (;;) {
-      x = bl_flat(r, a, b);
-      if (log(bl_unif(r)) <= 0.5 * (a * a - x * x)) break;
+  int tail = b - a > 1.0 / alpha;                       /* true for b = +inf */
+  int done = 0;
+  for (int k = 0; k < 4 && !done; ++k) {
+    double ua = U[2 * k], ub = U[2 * k + 1];
+    if (tail) {
+      x = a - log(ua) / alpha;
+      double d = x - alpha;
+      done = x <= b && log(ub) <= -0.5 * d * d;
+    } else {
+      x = a + (b - a) * ua;
+      done = log(ub) <= 0.5 * (a * a - x * x);
     }
   }
+  if (!done) x = tnorm_inv_right(a, b, U[8]);
   return flip ? -x : x;
 }

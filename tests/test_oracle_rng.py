@@ -88,7 +88,21 @@ def test_tnorm(oracle):
         a, b = stats.norm.cdf(lo), stats.norm.cdf(hi)
         if b - a > 1e-12:
             _ks(x, lambda v: (stats.norm.cdf(v) - a) / (b - a))
-    # degenerate interval returns the bound and consumes no uniform
-    r = oracle.rng(1)
-    assert oracle.lib().bl_tnorm(C.byref(r), 0.7, 0.7) == 0.7 and r.nunif == 0
-    assert oracle.lib().bl_tnorm(C.byref(r), 0.7, 0.7 + 1e-15) == 0.7 and r.nunif == 0
+    # a call always consumes exactly nine uniforms, whatever the bounds (stream never desynchronises)
+    for lo, hi in cases + [(0.7, 0.7), (0.7, 0.7 + 1e-15), (1.0, 0.5), (40.0, inf)]:
+        r = oracle.rng(1)
+        x = oracle.lib().bl_tnorm(C.byref(r), lo, hi)
+        assert r.nunif == 9
+        if hi <= lo:
+            assert x == lo
+    x = _draw(oracle, "bl_tnorm", 40.0, inf, n=2000)
+    assert x.min() >= 40.0 and abs(x.mean() - 40.0 - 1 / 40.0) < 2e-3
+
+
+def test_qnorm_as241(oracle):
+    L = oracle.lib()
+    L.bl_qnorm.restype = C.c_double
+    L.bl_qnorm.argtypes = [C.c_double]
+    ps = np.concatenate([10.0 ** np.linspace(-300, -1.2, 500), np.linspace(0.07, 0.93, 500)])
+    q = np.array([L.bl_qnorm(p) for p in ps])
+    assert np.allclose(q, stats.norm.ppf(ps), rtol=3e-15, atol=1e-15)
