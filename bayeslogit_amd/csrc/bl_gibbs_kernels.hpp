@@ -16,8 +16,9 @@ enum WeightMode : int {
 // summation order -- and therefore every bit of PP -- is reproducible).
 struct SweepPlan {
   int P = 0;
-  int fused = 0;          // 1: single-pass MFMA kernel (P in {16,32,48,64})
-  int nblocks = 0;        // workgroups of the sweep kernel
+  int fused = 0;          // 1: MFMA path (P in {16,32,48,64}), 0: generic kernels
+  int nblocks = 0;        // workgroups of the X'WX kernel (= number of partial slabs)
+  int nblocks_draw = 0;   // workgroups of the psi/omega kernel
   int nb = 0;             // fused: P/16
   int ntile = 0;          // generic: number of 64x64 output tiles (upper triangle)
   size_t partial_doubles = 0;   // workspace size
@@ -27,8 +28,8 @@ SweepPlan make_plan(int64_t N, int P, int num_cus);
 // One sweep over this rank's rows: psi_i = x_i.beta - off_i, omega_i by `mode`,
 // PPpart = sum_i omega_i x_i x_i' (full symmetric P x P, column-major).
 //   off     : per-row offset subtracted from psi (mlogit c_j), or nullptr
-//   w_store : where omega_i is written (N doubles), or nullptr.  The generic
-//             (non-fused) plan needs it and uses `w_scratch` when it is null.
+//   w_store : where omega_i is written (N doubles), or nullptr: `w_scratch` (N doubles)
+//             is used then (omega always passes through memory between the two passes).
 void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                   double* w_store, double* w_scratch, int64_t N, double* partial, double* PPpart, uint64_t seed,
                   uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s);

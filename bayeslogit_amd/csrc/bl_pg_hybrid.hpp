@@ -3,6 +3,7 @@
 #pragma once
 #include "bl_pg_alt.hpp"
 #include "bl_pg_sp.hpp"
+#include "bl_pg1_sm.hpp"
 
 namespace bl {
 

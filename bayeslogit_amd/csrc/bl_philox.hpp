@@ -1,0 +1,37 @@
+// bl_philox.hpp -- Philox4x32-10 block function and the 52-bit uniform of the stream
+// contract (DESIGN.md "RNG stream contract").  Portable (host + device).
+#pragma once
+#include "bl_portable.hpp"
+
+namespace bl {
+
+struct U4 { uint32_t x, y, z, w; };
+
+BL_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+BL_HD double u52(uint32_t hi, uint32_t lo)
+{
+  const uint64_t m = (((uint64_t)hi << 32) | lo) >> 12;
+  return ((double)m + 0.5) * 0x1.0p-52;
+}
+
+// counter words 0..2 of stream (idx, domain, epoch); word 3 is the block number
+BL_HD uint32_t ctr1_of(uint64_t idx, uint32_t domain) { return ((uint32_t)(idx >> 32) & 0x00FFFFFFu) | (domain << 24); }
+
+}  // namespace bl

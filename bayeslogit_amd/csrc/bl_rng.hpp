@@ -13,38 +13,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bl_philox.hpp"
+
 namespace bl {
 
 enum : uint32_t { DOM_DRAW = 0, DOM_BETA = 1, DOM_DATA = 2 };
 
 constexpr double kPi = 3.141592653589793238462643383279502884197;
-
-struct U4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                            uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    c1 = (uint32_t)p1;
-    c3 = (uint32_t)p0;
-    c0 = n0;
-    c2 = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  return U4{c0, c1, c2, c3};
-}
-
-__device__ __forceinline__ double u52(uint32_t hi, uint32_t lo)
-{
-  const uint64_t m = (((uint64_t)hi << 32) | lo) >> 12;
-  return ((double)m + 0.5) * 0x1.0p-52;
-}
 
 struct Stream {
   uint32_t k0, k1, c0, c1, c2, blk;

@@ -58,7 +58,7 @@ int bl_gibbs_create(bl_gibbs** out, int64_t N_local, int P, uint64_t idx0, uint6
   h->plan = blk::make_plan(N_local, P, num_cus());
   const size_t PPn = (size_t)P * P;
   const size_t colws = blk::colsum_ws_doubles(N_local, P);
-  const size_t wscr = h->plan.fused ? 0 : (size_t)(N_local > 0 ? N_local : 1);
+  const size_t wscr = (size_t)(N_local > 0 ? N_local : 1);
   const size_t work = blk::beta_work_doubles(P);
   const size_t total = 2 * PPn + 5 * (size_t)P + h->plan.partial_doubles + colws + wscr + work + 8;
   hipError_t e = hipMalloc((void**)&h->pool, total * sizeof(double));

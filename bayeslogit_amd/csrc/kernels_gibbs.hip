@@ -1,15 +1,21 @@
-// kernels_gibbs.hip -- kernels of the logistic Gibbs sweep on MI355X (gfx950):
-//   * k_sweep_fused<NB,MODE>: ONE pass over this rank's rows of X per sweep --
-//     psi = X beta, omega ~ PG(n, psi) one draw per lane, and the symmetric
-//     rank-N update X' Omega X on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64),
-//     with the 64-row tile held in registers between the two uses.
-//     Replaces gemm(psi) + draw_w + the P x N temp + syrk of Logit.hpp:283-301,431.
-//   * generic fallbacks for shapes the fused kernel does not take (P not a
-//     multiple of 16, or P > 64): k_psi_omega + k_xwx_tiles.
+// kernels_gibbs.hip -- kernels of the logistic Gibbs sweep on MI355X (gfx950).
+// One sweep over this rank's rows of X (Logit.hpp:426-431) is two streaming passes:
+//   pass 1  k_psi_omega_nb : psi = X beta by coalesced 16-byte loads + a 16-lane butterfly,
+//           then omega ~ PG(n, psi) by the wavefront work-queue state machine (one draw per
+//           lane, idle lanes refilled by ballot / prefix count); writes omega (8 B/row).
+//   pass 2  k_xwx_mfma     : X' Omega X as a rank-N update on the fp64 matrix pipe
+//           (v_mfma_f64_16x16x4_f64, upper-triangle 16x16 blocks), 2 waves per SIMD.
+// replacing gemm(psi) + draw_w + the P x N temp + syrk of Logit.hpp:283-301,431.
+// (A single-pass version that kept each 64-row tile in registers between the two uses was
+// built first and measured 5.8 ms/sweep at N=1e7, P=64: it is confined to one wave per SIMD
+// and the draw's dependent fp64 chains then run at latency, not throughput.  DESIGN.md.)
+//   * generic fallbacks for shapes the MFMA path does not take (P not a multiple of 16, or
+//     P > 64): k_psi_omega + k_xwx_tiles.
 //   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
 #include "bl_gibbs_kernels.hpp"
 #include "bl_pg_devroye.hpp"
+#include "bl_pg1_sm.hpp"
 #include "../../include/bayeslogit_hip.h"
 
 namespace {
@@ -25,9 +31,7 @@ template <int MODE>
 __device__ __forceinline__ double weight_of(double psi, double n, uint64_t seed, uint64_t idx, uint32_t epoch, int& st)
 {
   if (MODE == blk::W_DRAW) {
-    Stream r;
-    r.init(seed, idx, DOM_DRAW, epoch);
-    return pg_draw_devroye((int)n, psi, r, st);        // Logit.hpp:287
+    return pg1_draw_n((int)n, psi, seed, idx, DOM_DRAW, epoch, st);   // Logit.hpp:287
   } else {
     const double hpsi = psi * 0.5;                      // Logit.hpp:509-519
     if (fabs(hpsi) < 0.01)
@@ -36,7 +40,7 @@ __device__ __forceinline__ double weight_of(double psi, double n, uint64_t seed,
   }
 }
 
-// ============================================================ fused sweep kernel
+// ===================================================== P in {16,32,48,64}: two streaming passes
 // Column of X held by lane-column c in MFMA block q.  The assignment is chosen so
 // that a lane's loads are 16-byte vectors and a wavefront's load instruction covers
 // whole 128-byte lines; PP is un-permuted in the reduction epilogue.
@@ -49,144 +53,223 @@ __device__ __host__ __forceinline__ int colmap(int q, int c)
   return (q >> 1) * 32 + 2 * c + (q & 1);
 }
 
+// One group = 4 consecutive rows; lane (k = lane>>4, c = lane&15) takes row k of the group and
+// the NB columns colmap(q, c).  ok = row in range (out-of-range rows read row 0 and are zeroed).
 template <int NB>
-struct Tile {
-  double x[16][NB];   // [group of 4 rows][block]; statically indexed => registers
-};
-
-template <int NB>
-__device__ __forceinline__ void load_tile(Tile<NB>& t, const double* __restrict__ tX, int64_t tile, int64_t N, int k,
-                                          int c)
+__device__ __forceinline__ void load_group(double (&xg)[NB], const double* __restrict__ tX, int64_t row, bool ok, int c)
 {
   constexpr int P = 16 * NB;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int64_t row = tile * 64 + 4 * g + k;
-    const bool ok = row < N;
-    const double* p = tX + (size_t)(ok ? row : 0) * P;
-    if (NB == 1) {
-      const double v = p[c];
-      t.x[g][0] = ok ? v : 0.0;
-    } else {
-      const v2d v0 = *reinterpret_cast<const v2d*>(p + 2 * c);
-      t.x[g][0] = ok ? v0.x : 0.0;
-      t.x[g][1] = ok ? v0.y : 0.0;
-      if (NB == 3) {
-        const double v = p[32 + c];
-        t.x[g][2] = ok ? v : 0.0;
-      }
-      if (NB == 4) {
-        const v2d v1 = *reinterpret_cast<const v2d*>(p + 32 + 2 * c);
-        t.x[g][2] = ok ? v1.x : 0.0;
-        t.x[g][3] = ok ? v1.y : 0.0;
-      }
+  const double* p = tX + (size_t)(ok ? row : 0) * P;
+  if (NB == 1) {
+    const double v = p[c];
+    xg[0] = ok ? v : 0.0;
+  } else {
+    const v2d v0 = *reinterpret_cast<const v2d*>(p + 2 * c);
+    xg[0] = ok ? v0.x : 0.0;
+    xg[1] = ok ? v0.y : 0.0;
+    if (NB == 3) {
+      const double v = p[32 + c];
+      xg[2] = ok ? v : 0.0;
+    }
+    if (NB == 4) {
+      const v2d v1 = *reinterpret_cast<const v2d*>(p + 32 + 2 * c);
+      xg[2] = ok ? v1.x : 0.0;
+      xg[3] = ok ? v1.y : 0.0;
     }
   }
 }
 
+// ---- pass 1: psi = X beta (- off), omega ~ PG(n, psi) -> w[]          (Logit.hpp:431,283-289)
+// A wave takes super-tiles of kSuper rows.  Phase 1 streams the rows once (coalesced 16-byte
+// loads), forms psi by a 16-lane butterfly and leaves the proposal mass of every row in LDS;
+// phase 2 is the work-queue state machine of kernels_pg.hip's k_rpg_devroye.
+constexpr int kSuper = 512;
+
+template <int NB, int MODE>
+__global__ __launch_bounds__(kBlock) void k_psi_omega_nb(const double* __restrict__ tX,
+                                                         const double* __restrict__ nvec,
+                                                         const double* __restrict__ beta,
+                                                         const double* __restrict__ off,
+                                                         double* __restrict__ w, int64_t N, uint64_t seed,
+                                                         uint32_t epoch, uint64_t idx0, int* __restrict__ status)
+{
+  __shared__ double sZ[kBlock / 64][kSuper];
+  __shared__ double sM[kBlock / 64][kSuper];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane >> 4, c = lane & 15;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  int st_flags = 0;
+  double bq[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) bq[q] = beta[colmap<NB>(q, c)];
+
+  const int64_t nsuper = (N + kSuper - 1) / kSuper;
+  for (int64_t sp = (int64_t)blockIdx.x * (kBlock / 64) + wave; sp < nsuper; sp += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t base = sp * kSuper;
+    const int cnt = (int)((N - base) < kSuper ? (N - base) : kSuper);
+    // phase 1: psi for the rows of the super-tile, 64 rows (16 groups) at a time
+    for (int t0 = 0; t0 < cnt; t0 += 64) {
+      double psi = 0.0;
+#pragma unroll 4
+      for (int g = 0; g < 16; ++g) {
+        const int64_t row = base + t0 + 4 * g + k;
+        double xg[NB];
+        load_group<NB>(xg, tX, row, row < N, c);
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) part += xg[q] * bq[q];
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        part += __shfl_xor(part, 8);
+        psi = (c == g) ? part : psi;
+      }
+      const int slot = t0 + 4 * c + k;          // the row whose psi this lane kept
+      if (slot < cnt) {
+        if (off) psi -= off[base + slot];
+        if (MODE == blk::W_DRAW) {
+          const Pg1Par p = pg1_par(psi);
+          sZ[wave][slot] = p.Z;
+          sM[wave][slot] = p.mass;
+        } else {
+          w[base + slot] = weight_of<MODE>(psi, nvec[base + slot], seed, 0, epoch, st_flags);
+        }
+      }
+    }
+    if (MODE != blk::W_DRAW) continue;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // phase 2: work queue over the super-tile
+    int next = 0, q = -1, nrem = 0;
+    uint32_t c0 = 0, c1 = 0, blk = 0;
+    double sum = 0.0;
+    Pg1Par par{0.0, 1.0, 0.5};
+    Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
+    for (;;) {
+      const bool idle = q < 0;
+      const uint64_t im = __ballot(idle);
+      if (im != 0 && next < cnt) {
+        const int cand = next + __popcll(im & lt_mask);
+        if (idle && cand < cnt) {
+          int n = (int)nvec[base + cand];                       // (int) n(i), Logit.hpp:287
+          if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }      // PolyaGamma.cpp:128-135 (NTHROW)
+          q = cand;
+          nrem = n;
+          par.Z = sZ[wave][cand];
+          par.mass = sM[wave][cand];
+          par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
+          const uint64_t idx = idx0 + (uint64_t)(base + cand);
+          c0 = (uint32_t)idx;
+          c1 = ctr1_of(idx, DOM_DRAW);
+          blk = 0;
+          sum = 0.0;
+          sm.st = SM_BRANCH;
+        }
+        next += __popcll(im);
+      }
+      if (__ballot(q >= 0) == 0) {
+        if (next >= cnt) break;
+        continue;
+      }
+      if (q >= 0) {
+        const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
+        blk += 1;
+        if (pg1_advance(sm, par, u52(o.x, o.y), st_flags)) {
+          sum += 0.25 * sm.X;
+          if (--nrem == 0) { w[base + q] = sum; q = -1; }
+        }
+        if (q >= 0 && pg1_advance(sm, par, u52(o.z, o.w), st_flags)) {
+          sum += 0.25 * sm.X;
+          if (--nrem == 0) { w[base + q] = sum; q = -1; }
+        }
+        if (blk > 4000000u) { st_flags |= ST_ITER_CAP; w[base + q] = sum; q = -1; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (st_flags) atomicOr(status, st_flags);
+}
+
+// ---- pass 2: PPpart = sum_i w_i x_i x_i'  on the fp64 matrix pipe    (Logit.hpp:294-301)
+// A wave streams 64-row tiles; per group of 4 rows the lane holds x(row k, colmap(q,c)) and
+// issues one v_mfma_f64_16x16x4_f64 per upper-triangle block pair (A = w x_qa, B = x_qb).
 template <int NB>
 struct Acc {
   v4d a[NB * (NB + 1) / 2];
 };
 
-// psi for the lane's own observation (row 4c+k of the tile), then omega, then the
-// rank-64 update of the accumulators.
-template <int NB, int MODE>
-__device__ __forceinline__ void process_tile(const Tile<NB>& t, Acc<NB>& acc, const double (&bq)[NB], int64_t tile,
-                                             int64_t N, int lane, int k, int c, const double* __restrict__ nvec,
-                                             const double* __restrict__ off, double* __restrict__ w_store,
-                                             uint64_t seed, uint32_t epoch, uint64_t idx0, int& st)
-{
-  double psi = 0.0;
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    double part = 0.0;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) part += t.x[g][q] * bq[q];
-    part += __shfl_xor(part, 1);
-    part += __shfl_xor(part, 2);
-    part += __shfl_xor(part, 4);
-    part += __shfl_xor(part, 8);
-    psi = (c == g) ? part : psi;
-  }
-  const int64_t row = tile * 64 + 4 * c + k;
-  double omega = 0.0;
-  if (row < N) {
-    if (off) psi -= off[row];
-    omega = weight_of<MODE>(psi, nvec[row], seed, idx0 + (uint64_t)row, epoch, st);
-    if (w_store) w_store[row] = omega;
-  }
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const double wg = __shfl(omega, (lane & 48) | g);
-    double a[NB];
-#pragma unroll
-    for (int q = 0; q < NB; ++q) a[q] = wg * t.x[g][q];
-    int blkid = 0;
-#pragma unroll
-    for (int qa = 0; qa < NB; ++qa)
-#pragma unroll
-      for (int qb = qa; qb < NB; ++qb) {
-        acc.a[blkid] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], t.x[g][qb], acc.a[blkid], 0, 0, 0);
-        ++blkid;
-      }
-  }
-}
-
-// One workgroup = 4 wavefronts, one per SIMD, each streaming its own 64-row tiles:
-// wave w of block b takes tiles w_global, w_global + W, ... (W = 4 * gridDim.x).
-// The next tile's loads are issued before the current tile's draw + MFMA phases so
-// HBM latency hides under them (two register tiles, ping-pong).
-template <int NB, int MODE>
-__global__ __launch_bounds__(kBlock, 1) void k_sweep_fused(const double* __restrict__ tX,
-                                                           const double* __restrict__ nvec,
-                                                           const double* __restrict__ beta,
-                                                           const double* __restrict__ off,
-                                                           double* __restrict__ w_store, int64_t N,
-                                                           double* __restrict__ partial, uint64_t seed,
-                                                           uint32_t epoch, uint64_t idx0, int* __restrict__ status)
+template <int NB>
+__global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict__ tX, const double* __restrict__ w,
+                                                        int64_t N, double* __restrict__ partial)
 {
   constexpr int NBLK = NB * (NB + 1) / 2;
-  __shared__ double red[4][NBLK * 4][64];
+  __shared__ double red[2][NBLK * 4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, c = lane & 15;
   const int64_t ntiles = (N + 63) / 64;
   const int64_t W = (int64_t)gridDim.x * 4;
-  int st = 0;
-
-  double bq[NB];
-#pragma unroll
-  for (int q = 0; q < NB; ++q) bq[q] = beta[colmap<NB>(q, c)];
 
   Acc<NB> acc;
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc.a[b] = v4d{0.0, 0.0, 0.0, 0.0};
 
-  Tile<NB> ta, tb;
-  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (tile < ntiles) load_tile<NB>(ta, tX, tile, N, k, c);
-  while (tile < ntiles) {
-    if (tile + W < ntiles) load_tile<NB>(tb, tX, tile + W, N, k, c);
-    process_tile<NB, MODE>(ta, acc, bq, tile, N, lane, k, c, nvec, off, w_store, seed, epoch, idx0, st);
-    tile += W;
-    if (tile >= ntiles) break;
-    if (tile + W < ntiles) load_tile<NB>(ta, tX, tile + W, N, k, c);
-    process_tile<NB, MODE>(tb, acc, bq, tile, N, lane, k, c, nvec, off, w_store, seed, epoch, idx0, st);
-    tile += W;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += W) {
+    double x[16][NB];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t row = tile * 64 + 4 * g + k;
+      load_group<NB>(x[g], tX, row, row < N, c);
+    }
+    const int64_t myrow = tile * 64 + 4 * c + k;
+    const double omega = myrow < N ? w[myrow] : 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const double wg = __shfl(omega, (lane & 48) | g);
+      double a[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) a[q] = wg * x[g][q];
+      int blkid = 0;
+#pragma unroll
+      for (int qa = 0; qa < NB; ++qa)
+#pragma unroll
+        for (int qb = qa; qb < NB; ++qb) {
+          acc.a[blkid] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], x[g][qb], acc.a[blkid], 0, 0, 0);
+          ++blkid;
+        }
+    }
   }
 
-  // fixed-order in-block reduction of the four waves' accumulators
+  // fixed-order in-block reduction: (w0 + w2) + (w1 + w3)
+  if (wave >= 2) {
 #pragma unroll
-  for (int b = 0; b < NBLK; ++b)
+    for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][b * 4 + r][lane] = acc.a[b][r];
-  __syncthreads();
-  for (int e = threadIdx.x; e < NBLK * 4 * 64; e += kBlock) {
-    const int rr = e >> 6, ll = e & 63;
-    const double s = ((red[0][rr][ll] + red[1][rr][ll]) + red[2][rr][ll]) + red[3][rr][ll];
-    partial[(size_t)blockIdx.x * (NBLK * 4 * 64) + e] = s;
+      for (int r = 0; r < 4; ++r) red[wave - 2][b * 4 + r][lane] = acc.a[b][r];
   }
-  if (st) atomicOr(status, st);
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.a[b][r] += red[wave][b * 4 + r][lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[0][b * 4 + r][lane] = acc.a[b][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        partial[(size_t)blockIdx.x * (NBLK * 4 * 64) + (b * 4 + r) * 64 + lane] = acc.a[b][r] + red[0][b * 4 + r][lane];
+  }
 }
 
 // PP = sum over workgroups (fixed order) of the permuted MFMA blocks; un-permute,
@@ -586,11 +669,13 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
     if (t == 0) atomicOr(a.status, 8);
     return;
   }
+  // LDS layout: beta, z (P doubles each), perm (P ints), then L (P*P) when it fits.  The vectors
+  // are exchanged between lanes of the serial wave, which LDS orders and global memory does not.
   const bool l_in_lds = (size_t)P * P * 8 <= 128 * 1024;
-  double* Lm = l_in_lds ? lds : S;
-  double* sbeta = l_in_lds ? lds + (size_t)P * P : a.work + 2 * (size_t)P * P + 2 * P;
+  double* sbeta = lds;
   double* sz = sbeta + P;
   int* perm = reinterpret_cast<int*>(sz + P);
+  double* Lm = l_in_lds ? sz + P + (P + 1) / 2 + 1 : S;
   if (l_in_lds)
     for (int e = t; e < P * P; e += kBlock) Lm[e] = S[e];
   for (int j = t; j < P; j += kBlock) {
@@ -681,17 +766,18 @@ inline int grid_for(int64_t n, int block, int maxb)
 }
 
 template <int NB>
-void launch_fused_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
-                     const double* off, double* w_store, int64_t N, double* partial, double* PP, uint64_t seed,
-                     uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
+               double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
+               int mode, int* status, hipStream_t s)
 {
   constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
   if (mode == blk::W_DRAW)
-    hipLaunchKernelGGL((k_sweep_fused<NB, blk::W_DRAW>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, n, beta, off,
-                       w_store, N, partial, seed, epoch, idx0, status);
+    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_DRAW>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta,
+                       off, w, N, seed, epoch, idx0, status);
   else
-    hipLaunchKernelGGL((k_sweep_fused<NB, blk::W_EM>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, n, beta, off,
-                       w_store, N, partial, seed, epoch, idx0, status);
+    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta, off,
+                       w, N, seed, epoch, idx0, status);
+  hipLaunchKernelGGL((k_xwx_mfma<NB>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, partial);
   hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(kBlock), 0, s, partial, plan.nblocks, PP);
 }
 
@@ -709,8 +795,12 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     const int64_t ntiles = (N + 63) / 64;
     int64_t nb = (ntiles + 3) / 4;
     if (nb < 1) nb = 1;
-    if (nb > num_cus) nb = num_cus;       // one workgroup (4 waves, one per SIMD) per CU
+    if (nb > 2 * (int64_t)num_cus) nb = 2 * (int64_t)num_cus;   // pass 2: two 4-wave workgroups per CU
     p.nblocks = (int)nb;
+    int64_t nd = ((N + 511) / 512 + 3) / 4;
+    if (nd < 1) nd = 1;
+    if (nd > 4 * (int64_t)num_cus) nd = 4 * (int64_t)num_cus;   // pass 1: grid-stride over 512-row super-tiles
+    p.nblocks_draw = (int)nd;
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 4 * 64;
   } else {
     p.fused = 0;
@@ -730,16 +820,16 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
                   uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
 {
   const int P = plan.P;
+  double* w = w_store ? w_store : w_scratch;
   if (plan.fused) {
     switch (plan.nb) {
-      case 1: launch_fused_nb<1>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      case 2: launch_fused_nb<2>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      case 3: launch_fused_nb<3>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      default: launch_fused_nb<4>(plan, tX, n, beta, off, w_store, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+      case 1: launch_nb<1>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      case 2: launch_nb<2>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      case 3: launch_nb<3>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
+      default: launch_nb<4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
     }
     return;
   }
-  double* w = w_store ? w_store : w_scratch;
   const int g = grid_for(N, kBlock, 256 * 8);
   if (mode == W_DRAW)
     hipLaunchKernelGGL((k_psi_omega<W_DRAW>), dim3(g), dim3(kBlock), sizeof(double) * P, s, tX, n, beta, off, w, N, P,
@@ -797,8 +887,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   size_t lds = 0;
   if (mode == B_CONSTRAINED) {
     const size_t pp = (size_t)a.P * a.P * 8;
-    lds = (pp <= 128 * 1024 ? pp : 0) + 3 * (size_t)a.P * 8 + 64;
-    if (pp > 128 * 1024) lds = 0;
+    lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8 + (pp <= 128 * 1024 ? pp : 0);
   }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

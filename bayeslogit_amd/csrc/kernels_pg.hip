@@ -3,6 +3,7 @@
 // Code/C/LogitWrapper.cpp:39-167.  gfx950 only.
 #include "bl_host.hpp"
 #include "bl_pg_hybrid.hpp"
+#include "bl_pg1_sm.hpp"
 
 namespace {
 
@@ -12,25 +13,93 @@ constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond
 
 // ---------------------------------------------------------------- rpg_devroye
-// v1: one observation per lane per grid-stride step, per-lane rejection loops.
+// Wavefront work queue.  Each wave owns chunks of kChunk consecutive observations.
+//   phase 1 (all 64 lanes busy): coalesced load of z, proposal mass of every observation of
+//            the chunk (pg1_par: two Chebyshev sums), staged in LDS;
+//   phase 2: the lane-uniform state machine of bl_pg1_sm.hpp.  A lane whose draw has
+//            completed takes the next unstarted observation of the chunk: idle lanes are found
+//            with __ballot and numbered with a prefix popcount, so the wave keeps all lanes on
+//            the same transition body instead of waiting for its slowest rejection loop.
+// The stream belongs to the observation, so which lane draws it does not change the result.
+constexpr int kChunk = 512;
+
 __global__ __launch_bounds__(kBlock) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
                                                         int nscalar, const double* __restrict__ z, int64_t num,
                                                         uint64_t seed, uint32_t epoch, uint64_t idx0,
                                                         int* __restrict__ status)
 {
-  int st = 0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
-    const int n = nvec ? nvec[i] : nscalar;
-    double out = 0.0;
-    if (n != 0) {
-      Stream r;
-      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
-      out = pg_draw_devroye(n, z[i], r, st);
+  __shared__ double sZ[kBlock / 64][kChunk];
+  __shared__ double sM[kBlock / 64][kChunk];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int64_t nchunks = (num + kChunk - 1) / kChunk;
+  int st_flags = 0;
+  for (int64_t ch = (int64_t)blockIdx.x * (kBlock / 64) + wave; ch < nchunks; ch += (int64_t)gridDim.x * (kBlock / 64)) {
+    const int64_t base = ch * kChunk;
+    const int cnt = (int)((num - base) < kChunk ? (num - base) : kChunk);
+    for (int k = lane; k < cnt; k += 64) {
+      const Pg1Par p = pg1_par(z[base + k]);
+      sZ[wave][k] = p.Z;
+      sM[wave][k] = p.mass;
     }
-    x[i] = out;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    int next = 0;      // wave-uniform: first unstarted observation of the chunk
+    int q = -1;        // this lane's observation (slot in the chunk), -1 = idle
+    int nrem = 0;
+    uint32_t c0 = 0, c1 = 0, blk = 0;
+    double sum = 0.0;
+    Pg1Par par{0.0, 1.0, 0.5};
+    Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
+    for (;;) {
+      const bool idle = q < 0;
+      const uint64_t im = __ballot(idle);
+      if (im != 0 && next < cnt) {
+        const int cand = next + __popcll(im & lt_mask);
+        if (idle && cand < cnt) {
+          int n = nvec ? nvec[base + cand] : nscalar;
+          if (n == 0) {
+            x[base + cand] = 0.0;                 // LogitWrapper.cpp:74-77
+          } else {
+            if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }
+            q = cand;
+            nrem = n;
+            par.Z = sZ[wave][cand];
+            par.mass = sM[wave][cand];
+            par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
+            const uint64_t idx = idx0 + (uint64_t)(base + cand);
+            c0 = (uint32_t)idx;
+            c1 = ctr1_of(idx, DOM_DRAW);
+            blk = 0;
+            sum = 0.0;
+            sm.st = SM_BRANCH;
+          }
+        }
+        next += __popcll(im);
+      }
+      if (__ballot(q >= 0) == 0) {
+        if (next >= cnt) break;
+        continue;
+      }
+      if (q >= 0) {
+        const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
+        blk += 1;
+        if (pg1_advance(sm, par, u52(o.x, o.y), st_flags)) {
+          sum += 0.25 * sm.X;
+          if (--nrem == 0) { x[base + q] = sum; q = -1; }
+        }
+        if (q >= 0 && pg1_advance(sm, par, u52(o.z, o.w), st_flags)) {
+          sum += 0.25 * sm.X;
+          if (--nrem == 0) { x[base + q] = sum; q = -1; }
+        }
+        if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  if (st) atomicOr(status, st);
+  if (st_flags) atomicOr(status, st_flags);
 }
 
 // ------------------------------------------------ rpg_alt / rpg_sp / rpg_gamma
@@ -111,7 +180,9 @@ __global__ __launch_bounds__(kBlock) void k_rpg_hybrid_class(double* __restrict_
     const double b = h[i];
     if (pg_class(b) != CLS) continue;
     double out = 0.0;
-    if (CLS != CLS_ZERO) {
+    if (CLS == CLS_DEVROYE) {
+      out = pg1_draw_n((int)b, z[i], seed, idx0 + (uint64_t)i, DOM_DRAW, epoch, st);
+    } else if (CLS != CLS_ZERO) {
       Stream r;
       r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
       out = pg_hybrid_class(CLS, b, z[i], r, st);

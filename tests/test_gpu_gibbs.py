@@ -31,8 +31,8 @@ def shard_of(X, y, n, gpu, seed, idx0=0):
     return D.GibbsShard(t(X), t(y), t(n), seed=seed, idx0=idx0)
 
 
-@pytest.mark.parametrize("N,P", [(1000, 64), (64, 64), (65, 64), (4097, 32), (777, 16), (300, 48), (500, 10),
-                                 (200, 1), (333, 70), (150, 130)])
+@pytest.mark.parametrize("N,P", [(1000, 64), (64, 64), (65, 64), (4097, 32), (777, 16), (300, 48), (1500, 48),
+                                 (500, 10), (200, 1), (333, 70), (2000, 70), (150, 130), (2600, 130), (20000, 130)])
 def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     """fused MFMA path (P in 16,32,48,64) and the generic path (other P), ragged N included."""
     from bayeslogit_amd import device as D
@@ -65,10 +65,17 @@ def test_one_sweep_matches_oracle(gpu, oracle, N, P):
         if con:
             assert np.all(bg[:-1] >= -1e-12)                         # Logit.hpp:383-391
         # The coordinate-wise constrained draw is a pathwise-unstable map when many constraints bind
-        # (N ~ P with a prior mean pushing below zero): a 1e-16 relative perturbation of PP moves the
-        # ORACLE's own output by O(1) there ("constrained draw conditioning").  Exact
-        # comparison is therefore made where the map is well conditioned (N >= 4P).
-        if con == 0 or N >= 4 * P:
+        # (N ~ P, or large P: P^2 serial coordinate moves): a 1e-15 relative perturbation of PP can move
+        # the ORACLE's own output by O(1) ("constrained draw conditioning").  The exact
+        # comparison is made where the oracle itself is stable under such a perturbation.
+        stable = True
+        if con:
+            E = np.random.default_rng(0).normal(size=(P, P)) * 1e-15
+            bo2 = oracle.draw_beta((PPo + P0) * (1 + (E + E.T) / 2), bPo, beta0, 99, 4, con)
+            stable = np.abs(bo2 - bo).max() < 1e-10
+            if N >= 10 * P and P <= 70:
+                assert stable                                        # these cases must stay checkable
+        if stable:
             assert np.abs(bg - bo).max() < 1e-9, (con, np.abs(bg - bo).max())
         else:
             assert np.all(np.isfinite(bg))
