@@ -728,6 +728,363 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
   for (int j = t; j < P; j += kBlock) a.beta_out[j] = sbeta[j];
 }
 
+// ============================================= P x P stage, P <= 64: everything on chip
+// k_beta64 does the same four jobs as k_beta with the three P x P matrices in LDS (leading
+// dimension P+1: conflict-free rows and columns) and, for the constrained draw, a serial
+// coordinate loop stripped to its dependent chain:
+//   * every random input of the draw is generated BEFORE the loop, in parallel (possible
+//     because a tnorm call owns exactly nine uniforms whatever its bounds): the P-1 swap
+//     targets of each random scan and, per tnorm call, the four proposal pairs with their
+//     logs and Box-Muller normal already taken;
+//   * lane j of one wavefront owns row j (beta_j, z_j in registers); the bounds of a move are
+//     a 64-lane max/min by DPP (no LDS round trip), with 1/L precomputed elementwise.
+#define L_(M, i, j) ((M)[(i) + (j) * ld])
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// all-lanes max / min of a wavefront: butterfly inside each row of 16 lanes, then the 4 rows
+__device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
+{
+  mx = fmax(mx, dpp_f64<0xB1>(mx));  mn = fmin(mn, dpp_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
+  mx = fmax(mx, dpp_f64<0x4E>(mx));  mn = fmin(mn, dpp_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
+  mx = fmax(mx, dpp_f64<0x141>(mx)); mn = fmin(mn, dpp_f64<0x141>(mn));   // row_half_mirror
+  mx = fmax(mx, dpp_f64<0x140>(mx)); mn = fmin(mn, dpp_f64<0x140>(mn));   // row_mirror
+  const double a0 = readlane_f64(mx, 0), a1 = readlane_f64(mx, 16), a2 = readlane_f64(mx, 32), a3 = readlane_f64(mx, 48);
+  const double b0 = readlane_f64(mn, 0), b1 = readlane_f64(mn, 16), b2 = readlane_f64(mn, 32), b3 = readlane_f64(mn, 48);
+  mx = fmax(fmax(a0, a1), fmax(a2, a3));
+  mn = fmin(fmin(b0, b1), fmin(b2, b3));
+}
+
+// tnorm from the pre-generated record of the call: R[4k+0..3] = ua, log ua, log ub, Box-Muller
+// normal of attempt k; R[16] = fallback uniform.  Same decisions and values as bl::tnorm.
+__device__ inline double tnorm_pre(const double* __restrict__ R, double lo, double hi)
+{
+  const bool lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
+  if (lo_inf && hi_inf) return qnorm(R[16]);
+  if (!(hi - lo > 0.0)) return lo;
+  if (lo <= 0.0 && hi >= 0.0) {
+    const bool wide = hi - lo > 2.5066282746310002;
+    for (int k = 0; k < 4; ++k) {
+      if (wide) {
+        const double x = R[4 * k + 3];
+        if (x >= lo && x <= hi) return x;
+      } else {
+        const double x = lo + (hi - lo) * R[4 * k];
+        if (R[4 * k + 2] <= -0.5 * x * x) return x;
+      }
+    }
+    const double pl = lo_inf ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
+    const double ph = hi_inf ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
+    double x = qnorm(pl + R[16] * (ph - pl));
+    x = x < lo ? lo : x;
+    x = x > hi ? hi : x;
+    return x;
+  }
+  const bool flip = hi < 0.0;
+  const double a = flip ? -hi : lo, b = flip ? -lo : hi;
+  const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
+  const bool tail = b - a > 1.0 / alpha;
+  double x = a;
+  bool done = false;
+  for (int k = 0; k < 4 && !done; ++k) {
+    if (tail) {
+      x = a - R[4 * k + 1] / alpha;
+      const double d = x - alpha;
+      done = x <= b && R[4 * k + 2] <= -0.5 * d * d;
+    } else {
+      x = a + (b - a) * R[4 * k];
+      done = R[4 * k + 2] <= 0.5 * (a * a - x * x);
+    }
+  }
+  if (!done) x = tnorm_inv_right(a, b, R[16]);
+  return flip ? -x : x;
+}
+
+// uniform number `ui` of stream (seed, 0, DOM_BETA, epoch)
+__device__ __forceinline__ double beta_stream_unif(uint64_t seed, uint32_t epoch, uint32_t ui)
+{
+  const U4 o = philox4x32_10(0u, ctr1_of(0, DOM_BETA), epoch, ui >> 1, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (ui & 1u) ? u52(o.z, o.w) : u52(o.x, o.y);
+}
+
+// whole-workgroup dense helpers on LDS matrices with leading dimension ld
+__device__ bool lds_chol_upper(double* A, int P, int ld, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(A, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) L_(A, k, k) = d;
+    for (int j = k + 1 + t; j < P; j += kBlock) L_(A, k, j) = L_(A, k, j) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i <= j) L_(A, i, j) -= L_(A, k, i) * L_(A, k, j);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+__device__ bool lds_chol_lower(double* S, int P, int ld, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(S, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) L_(S, k, k) = d;
+    for (int i = k + 1 + t; i < P; i += kBlock) L_(S, i, k) = L_(S, i, k) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i >= j) L_(S, i, j) -= L_(S, i, k) * L_(S, j, k);
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    if (i < j) L_(S, i, j) = 0.0;
+  }
+  __syncthreads();
+  return true;
+}
+__device__ void lds_solve_Ut(const double* U, double* B, int P, int ld, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    const double d = L_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + c * ldb] /= d;
+    __syncthreads();
+    const int m = P - i - 1;
+    for (int e = t; e < m * nrhs; e += kBlock) {
+      const int j = i + 1 + e % m, c = e / m;
+      B[j + c * ldb] -= L_(U, i, j) * B[i + c * ldb];
+    }
+    __syncthreads();
+  }
+}
+__device__ void lds_solve_U(const double* U, double* B, int P, int ld, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = P - 1; i >= 0; --i) {
+    const double d = L_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + c * ldb] /= d;
+    __syncthreads();
+    for (int e = t; e < i * nrhs; e += kBlock) {
+      const int j = e % i, c = e / i;
+      B[j + c * ldb] -= L_(U, j, i) * B[i + c * ldb];
+    }
+    __syncthreads();
+  }
+}
+__device__ void lds_solve_L(const double* Lm, double* b, int P, int ld)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    if (t == 0) b[i] /= L_(Lm, i, i);
+    __syncthreads();
+    for (int j = i + 1 + t; j < P; j += kBlock) b[j] -= L_(Lm, j, i) * b[i];
+    __syncthreads();
+  }
+}
+
+constexpr int kRec = 17;   // doubles per pre-generated tnorm record
+
+__global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
+{
+  extern __shared__ double lds[];
+  const int P = a.P, t = threadIdx.x, ld = P + 1;
+  double* A = lds;                       // PP -> U
+  double* S = A + P * ld;                // PP^{-1} -> L
+  double* Ri = S + P * ld;               // 1/L elementwise (constrained mode)
+  double* mP = Ri + P * ld;
+  double* zz = mP + P;
+  int* perm = reinterpret_cast<int*>(zz + P);       // P ints
+  double* rec = a.work;                             // P*P records of kRec doubles
+  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);   // P*(P-1) swap targets
+  int* sig = swp + P * P;                            // sig[k][.]: scan k's swaps applied to the identity
+  int* ptab = sig + P * P;                           // ptab[k][i]: coordinate visited at step i of scan k
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
+  }
+
+  if (mode == blk::B_CONSTRAINED) {
+    // ---- all random input of the draw, in stream order (oracle/logit_gibbs.c: per scan k:
+    //      P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms each) ----
+    const uint32_t per_scan = (uint32_t)(10 * P - 1);
+    for (int e = t; e < P * (P - 1); e += kBlock) {
+      const int k = e / (P - 1), i = e % (P - 1);
+      const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
+      swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P), Logit.hpp:375
+    }
+    for (int e = t; e < P * P; e += kBlock) {
+      const int k = e / P, i = e % P;
+      const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+      double* R = rec + (size_t)e * kRec;
+      for (int m = 0; m < 4; ++m) {
+        const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+        const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+        const double lua = log(ua);
+        R[4 * m] = ua;
+        R[4 * m + 1] = lua;
+        R[4 * m + 2] = log(ub);
+        R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+      }
+      R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+    }
+  }
+  __syncthreads();
+  if (mode == blk::B_CONSTRAINED) {
+    // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel ...
+    if (t < P) {
+      int* sg = sig + t * P;
+      for (int i = 0; i < P; ++i) sg[i] = i;
+      for (int i = 0; i < P - 1; ++i) {
+        const int j = swp[t * (P - 1) + i];
+        const int tmp = sg[i];
+        sg[i] = sg[j];
+        sg[j] = tmp;
+      }
+    }
+    __syncthreads();
+    // ... then composed in scan order: `is` persists across scans (Logit.hpp:368-377)
+    for (int k = 0; k < P; ++k) {
+      if (t < P) ptab[k * P + t] = (k == 0) ? sig[t] : ptab[(k - 1) * P + sig[k * P + t]];
+      __syncthreads();
+    }
+  }
+
+  if (!lds_chol_upper(A, P, ld, &bad)) {
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, 8);
+    return;
+  }
+
+  if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
+    for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+    if (mode == blk::B_MVN)
+      for (int i = t; i < P; i += kBlock) {
+        // eps_i = r.norm(0,1) in stream order: normal i is exactly Philox block i
+        const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * i), u2 = beta_stream_unif(a.seed, a.epoch, 2 * i + 1);
+        zz[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+      }
+    __syncthreads();
+    lds_solve_Ut(A, mP, P, ld, 1, P);
+    lds_solve_U(A, mP, P, ld, 1, P);
+    if (mode == blk::B_MVN) {
+      lds_solve_U(A, zz, P, ld, 1, P);
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = zz[j] + mP[j];
+    } else {
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = mP[j];
+    }
+    return;
+  }
+
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    L_(S, i, j) = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  lds_solve_Ut(A, S, P, ld, P, ld);
+  lds_solve_U(A, S, P, ld, P, ld);
+
+  if (mode == blk::B_FROM_LIK) {
+    for (int i = t; i < P; i += kBlock) {
+      double s = 0.0;
+      for (int k2 = 0; k2 < P; ++k2) s += L_(S, i, k2) * a.bP[k2];
+      mP[i] = s;
+      const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * i), u2 = beta_stream_unif(a.seed, a.epoch, 2 * i + 1);
+      zz[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+    }
+    __syncthreads();
+    if (!lds_chol_lower(S, P, ld, &bad)) {
+      __syncthreads();
+      if (t == 0) atomicOr(a.status, 8);
+      return;
+    }
+    for (int i = t; i < P; i += kBlock) {
+      double le = 0.0;
+      for (int k2 = 0; k2 <= i; ++k2) le += L_(S, i, k2) * zz[k2];
+      a.beta_out[i] = le + mP[i];
+    }
+    return;
+  }
+
+  // ---- B_CONSTRAINED, Logit.hpp:322-400 ----
+  for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+  __syncthreads();
+  lds_solve_Ut(A, mP, P, ld, 1, P);
+  lds_solve_U(A, mP, P, ld, 1, P);
+  if (!lds_chol_lower(S, P, ld, &bad)) {
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, 8);
+    return;
+  }
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    L_(Ri, i, j) = 1.0 / L_(S, i, j);
+  }
+  for (int j = t; j < P; j += kBlock) {
+    zz[j] = a.beta_prev[j] - mP[j];
+    perm[j] = j;
+  }
+  __syncthreads();
+  lds_solve_L(S, zz, P, ld);
+
+  if (t < 64) {
+    const int lane = t;
+    const bool row = lane < P;
+    double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j
+    double zj = row ? zz[lane] : 0.0;                // z_j
+    const double inf = __builtin_huge_val();
+    for (int k = 0; k < P; ++k) {
+      for (int i = 0; i < P; ++i) {
+        const int c = __builtin_amdgcn_readfirstlane(ptab[k * P + i]);
+        const double* R = rec + ((size_t)k * P + i) * kRec;
+        const double z1 = readlane_f64(zj, c);
+        const double l1 = row ? L_(S, lane, c) : 0.0;
+        const double ri = row ? L_(Ri, lane, c) : 0.0;
+        const double c1 = z1 - bj * ri;
+        const bool in = row && lane >= c && lane < P - 1;
+        double lo = (in && l1 > 0.0) ? c1 : -inf;
+        double hi = (in && l1 < 0.0) ? c1 : inf;
+        wave_maxmin(lo, hi);
+        const double z2 = tnorm_pre(R, lo, hi);
+        const double dz = z2 - z1;
+        if (row && lane >= c) bj += l1 * dz;
+        if (lane == c) zj = z2;
+      }
+    }
+    if (row) a.beta_out[lane] = bj;
+  }
+}
+#undef L_
+
 __global__ void k_maxabsdiff(const double* a, const double* b, int P, double* out)
 {
   __shared__ double sm[kBlock];
@@ -880,10 +1237,23 @@ void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_o
   hipLaunchKernelGGL(k_mlogit_offset, dim3(grid_for(N, kBlock, 256 * 8)), dim3(kBlock), 0, s, XB, N, J, j, c_out);
 }
 
-size_t beta_work_doubles(int P) { return 2 * (size_t)P * P + 6 * (size_t)P + 64; }
+size_t beta_work_doubles(int P)
+{
+  const size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
+  const size_t small = (size_t)P * P * kRec + 3 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
+  return generic > small ? generic : small;
+}
 
 void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
 {
+  if (a.P <= 64) {
+    const int ld = a.P + 1;
+    const size_t lds = (3 * (size_t)a.P * ld + 2 * (size_t)a.P) * 8 + 2 * (size_t)a.P * 4 + 16;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_beta64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
+    return;
+  }
   size_t lds = 0;
   if (mode == B_CONSTRAINED) {
     const size_t pp = (size_t)a.P * a.P * 8;
