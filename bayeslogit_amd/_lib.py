@@ -27,6 +27,7 @@ SIGNATURES = {
     "bl_set_device": (C.c_int, [C.c_int]),
     "bl_set_seed": (None, [c_u64]),
     "bl_get_seed": (c_u64, []),
+    "bl_set_seed_from_unif": (None, [c_dp]),
     "bl_get_epoch": (c_u32, []),
     "bl_set_constrain": (None, [C.c_int]),
     "rpg_gamma": (None, [c_dp, c_dp, c_dp, c_ip, c_ip]),

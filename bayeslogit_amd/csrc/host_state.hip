@@ -126,6 +126,11 @@ void bl_set_seed(uint64_t seed)
   g_epoch = 0;
 }
 uint64_t bl_get_seed(void) { return g_seed.load(); }
+void bl_set_seed_from_unif(double* u)
+{
+  const uint64_t hi = (uint64_t)(u[0] * 4294967296.0) & 0xFFFFFFFFull, lo = (uint64_t)(u[1] * 4294967296.0) & 0xFFFFFFFFull;
+  bl_set_seed((hi << 32) | lo);
+}
 uint32_t bl_get_epoch(void) { return g_epoch.load(); }
 void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
 

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   }
 
   if (mode == blk::B_CONSTRAINED) {
-    // ---- all random input of the draw, in stream order (oracle/logit_gibbs.c: per scan k:
+    // ---- all random input of the draw, in stream order (stream contract, DESIGN.md section 2: per scan k:
     //      P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms each) ----
     const uint32_t per_scan = (uint32_t)(10 * P - 1);
     for (int e = t; e < P * (P - 1); e += kBlock) {

@@ -51,6 +51,9 @@ int         bl_set_device(int device);
  * unif_rand() inside its own Get/PutRNGstate bracket. */
 void     bl_set_seed(uint64_t seed);      /* also resets the call epoch to 0 */
 uint64_t bl_get_seed(void);
+/* .C-callable seeding for an R shim: u[0], u[1] are two unif_rand() values in [0,1); the
+ * seed is floor(u[0] 2^32) << 32 | floor(u[1] 2^32).  Resets the call epoch like bl_set_seed. */
+void     bl_set_seed_from_unif(double *u);
 uint32_t bl_get_epoch(void);
 /* beta draw used by gibbs(): 1 = the fork's active sign-constrained coordinate
  * draw (Logit.hpp:322-400, call site :429), 0 = unconstrained MVN (Logit.hpp:291-320).

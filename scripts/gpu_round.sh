@@ -1,6 +1,8 @@
 #!/bin/bash
-# One GPU-box session: parity tests, bench, kernel-trace profile.  Stops after any step that times out.
+# One GPU-box session: parity tests, smoke, bench, kernel-trace profile, PMC passes.
+# Stops after any step that times out.  Usage: bash scripts/gpu_round.sh [tag]
 set -o pipefail
+TAG=${1:-r01}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 step() {  # name, timeout, command...
@@ -9,16 +11,22 @@ step() {  # name, timeout, command...
   timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
   local rc=$?
   echo "== $name rc=$rc" | tee -a gpurun_out/round.log
-  tail -n 6 "gpurun_out/$name.log"
+  tail -n 4 "gpurun_out/$name.log" | cut -c1-400
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/round.log; exit 1; fi
   return 0
 }
 : > gpurun_out/round.log
-step pytest_gpu 700 python -m pytest tests -m gpu -q -x
+step pytest_gpu 600 python -m pytest tests -m gpu -q
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
 step bench 400 python bench.py --mixed
-PROF=gpurun_out/prof_bench
-rm -rf $PROF
-step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $PROF -- python3 bench.py --steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu
-find $PROF -name "*kernel_stats.csv" | head -3 | while read f; do echo "--- $f"; head -30 "$f"; done | tee gpurun_out/kernel_stats_head.txt
+BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu"
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_*_$TAG
+step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py $BARGS
+find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" gpurun_out/kernel_stats_$TAG.csv; done
+PARGS="--steps 2 --warmup 1 --gibbs-sweeps 3 --no-cpu"
+step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py $PARGS
+step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py $PARGS
+step pmc_valu 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu_$TAG -- python3 bench.py $PARGS
+python3 scripts/summarize_pmc.py $TAG > gpurun_out/pmc_summary_$TAG.txt 2>&1
+cat gpurun_out/pmc_summary_$TAG.txt | cut -c1-300
 exit 0
