@@ -8,8 +8,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BL_HD __host__ __device__ __forceinline__
+#define BL_HD_COLD __host__ __device__ inline __attribute__((noinline))
 #else
 #define BL_HD inline
+#define BL_HD_COLD inline
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BL_COSPI(x) cospi(x)

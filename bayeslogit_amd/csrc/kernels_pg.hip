@@ -23,7 +23,7 @@ constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride
 // The stream belongs to the observation, so which lane draws it does not change the result.
 constexpr int kChunk = 512;
 
-__global__ __launch_bounds__(kBlock) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
+__global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
                                                         int nscalar, const double* __restrict__ z, int64_t num,
                                                         uint64_t seed, uint32_t epoch, uint64_t idx0,
                                                         int* __restrict__ status)
@@ -86,13 +86,15 @@ __global__ __launch_bounds__(kBlock) void k_rpg_devroye(double* __restrict__ x, 
       if (q >= 0) {
         const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
         blk += 1;
-        if (pg1_advance(sm, par, u52(o.x, o.y), st_flags)) {
-          sum += 0.25 * sm.X;
-          if (--nrem == 0) { x[base + q] = sum; q = -1; }
-        }
-        if (q >= 0 && pg1_advance(sm, par, u52(o.z, o.w), st_flags)) {
-          sum += 0.25 * sm.X;
-          if (--nrem == 0) { x[base + q] = sum; q = -1; }
+        double u = u52(o.x, o.y);
+        const double u_second = u52(o.z, o.w);
+#pragma unroll 1
+        for (int half = 0; half < 2 && q >= 0; ++half) {
+          if (pg1_advance(sm, par, u, st_flags)) {
+            sum += 0.25 * sm.X;
+            if (--nrem == 0) { x[base + q] = sum; q = -1; }
+          }
+          u = u_second;
         }
         if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
       }

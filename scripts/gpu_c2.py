@@ -1,0 +1,14 @@
+"""C2 only (for PMC runs): two launches each of z~U(0,4) and z=0."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from bayeslogit_amd import device as D
+dev = torch.device("cuda:0")
+n = 100_000_000
+z = torch.empty(n, dtype=torch.float64, device=dev); D.fill_unif(z, 0.0, 4.0, 20240001)
+x = torch.empty_like(z)
+for _ in range(2): D.rpg_devroye(z, 1, seed=20240002, out=x)
+torch.cuda.synchronize()
+z.zero_()
+for _ in range(2): D.rpg_devroye(z, 1, seed=20240003, out=x)
+torch.cuda.synchronize(); D.sync_status(); print("ok", x.mean().item())

@@ -36,3 +36,9 @@ long sm_count_transitions(double z, long ndraws, unsigned long long seed)
   return total;
 }
 }
+
+#include "../../bayeslogit_amd/csrc/bl_fastmath.hpp"
+extern "C" {
+double fm_log(double x) { return bl::bl_log(x); }
+double fm_exp(double x) { return bl::bl_exp(x); }
+}

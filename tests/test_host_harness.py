@@ -71,3 +71,25 @@ def test_transitions_per_draw(harness):
     for z, lo, hi in ((0.0, 4.4, 4.8), (2.0, 5.2, 5.7), (4.0, 5.0, 5.6)):
         t = harness.sm_count_transitions(z, 100000, 5) / 100000
         assert lo < t < hi, (z, t)
+
+
+def test_fastmath_log_exp_accuracy(harness):
+    """bl_fastmath.hpp: < 1.5 ulp against 40-digit references on the ranges the samplers use."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    harness.fm_log.restype = C.c_double
+    harness.fm_log.argtypes = [C.c_double]
+    harness.fm_exp.restype = C.c_double
+    harness.fm_exp.argtypes = [C.c_double]
+    rng = np.random.default_rng(0)
+
+    def ulps(got, ex):
+        return abs(mp.mpf(got) - ex) / (mp.mpf(2) ** (mp.floor(mp.log(abs(ex), 2)) - 52))
+
+    xs = np.concatenate([rng.uniform(0, 1, 3000), 2.0 ** rng.uniform(-60, 60, 1000), rng.uniform(0.99, 1.01, 1000),
+                         [2.0 ** -53, 1.4142135623730951, 0.7071067811865476, 1e300, 1e-300]])
+    assert max(ulps(harness.fm_log(x), mp.log(mp.mpf(x))) for x in xs) < 1.5
+    assert harness.fm_log(1.0) == 0.0
+    xs = np.concatenate([rng.uniform(-40, 0, 3000), rng.uniform(-700, 700, 1000), rng.uniform(-1e-3, 1e-3, 500), [0.0]])
+    assert max(ulps(harness.fm_exp(x), mp.exp(mp.mpf(x))) for x in xs) < 1.5
+    assert harness.fm_exp(-800.0) == 0.0 and np.isinf(harness.fm_exp(710.0))
