@@ -60,6 +60,7 @@ struct BetaArgs {
   uint64_t seed;
   uint32_t epoch;
   int* status;             // BL_ERR_NOT_PD flag word (host-visible int, device memory)
+  unsigned long long* dbg = nullptr;   // optional: 8 phase stamps (100 MHz wall clock), development aid
 };
 size_t beta_work_doubles(int P);
 enum BetaMode : int {

@@ -2,6 +2,7 @@
 // (include/bayeslogit_hip.h).  Mirrors the sweep structure and slot semantics of
 // Code/C/Logit.hpp:402-481 and Code/C/MultLogit.hpp:261-372; all arithmetic runs in
 // the kernels of kernels_gibbs.hip.  There is no CPU compute path.
+#include <cstdlib>
 #include <vector>
 
 #include "bl_gibbs_kernels.hpp"
@@ -174,8 +175,23 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
   a.seed = h->seed;
   a.epoch = sweep;
   a.status = blh::status_word(h->stream);
+  static const bool dbg = getenv("BL_BETA_DEBUG") != nullptr;   // development aid: phase timing of the beta stage
+  static unsigned long long* dbuf = nullptr;
+  if (dbg) {
+    if (!dbuf) (void)hipMalloc((void**)&dbuf, 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbuf, 0, 8 * sizeof(unsigned long long), h->stream);
+    a.dbg = dbuf;
+  }
   blk::launch_beta(a, constrain ? blk::B_CONSTRAINED : blk::B_MVN, h->stream);
   BL_HIP_TRY(hipGetLastError());
+  if (dbg) {
+    unsigned long long st[8];
+    (void)hipMemcpyAsync(st, dbuf, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    fprintf(stderr, "beta stage (us): init+pregen %.1f perm %.1f chol %.1f inverse %.1f chol2+prep %.1f serial %.1f\n",
+            (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0, (st[4] - st[3]) / 100.0,
+            (st[5] - st[4]) / 100.0, (st[6] - st[5]) / 100.0);
+  }
   return BL_OK;
 }
 

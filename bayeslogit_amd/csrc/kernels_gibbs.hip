@@ -753,61 +753,96 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
                           __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// all-lanes max / min of a wavefront: butterfly inside each row of 16 lanes, then the 4 rows
+// raw v_max_f64 / v_min_f64 (operands are never NaN here; skips the canonicalising pre-pass
+// that fmax()/fmin() lower to)
+__device__ __forceinline__ double vmax64(double a, double b)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin64(double a, double b)
+{
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_rm(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// max of mx and min of mn over the 64 lanes, returned wave-uniform: butterfly inside each row
+// of 16 lanes (4 DPP levels), then row_bcast15 / row_bcast31 fold the four rows into row 3.
+// (A float-key fast path -- one VOP2-DPP op per level, winner located by ballot -- was tried and
+// measured slower: its VALU->SGPR->branch crossings cost more than the 64-bit moves they save.)
 __device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
 {
-  mx = fmax(mx, dpp_f64<0xB1>(mx));  mn = fmin(mn, dpp_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
-  mx = fmax(mx, dpp_f64<0x4E>(mx));  mn = fmin(mn, dpp_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
-  mx = fmax(mx, dpp_f64<0x141>(mx)); mn = fmin(mn, dpp_f64<0x141>(mn));   // row_half_mirror
-  mx = fmax(mx, dpp_f64<0x140>(mx)); mn = fmin(mn, dpp_f64<0x140>(mn));   // row_mirror
-  const double a0 = readlane_f64(mx, 0), a1 = readlane_f64(mx, 16), a2 = readlane_f64(mx, 32), a3 = readlane_f64(mx, 48);
-  const double b0 = readlane_f64(mn, 0), b1 = readlane_f64(mn, 16), b2 = readlane_f64(mn, 32), b3 = readlane_f64(mn, 48);
-  mx = fmax(fmax(a0, a1), fmax(a2, a3));
-  mn = fmin(fmin(b0, b1), fmin(b2, b3));
+  mx = vmax64(mx, dpp_f64<0xB1>(mx));  mn = vmin64(mn, dpp_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
+  mx = vmax64(mx, dpp_f64<0x4E>(mx));  mn = vmin64(mn, dpp_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
+  mx = vmax64(mx, dpp_f64<0x141>(mx)); mn = vmin64(mn, dpp_f64<0x141>(mn));   // row_half_mirror
+  mx = vmax64(mx, dpp_f64<0x140>(mx)); mn = vmin64(mn, dpp_f64<0x140>(mn));   // row_mirror
+  mx = vmax64(mx, dpp_f64_rm<0x142, 0xa>(mx)); mn = vmin64(mn, dpp_f64_rm<0x142, 0xa>(mn));   // row_bcast15 -> rows 1,3
+  mx = vmax64(mx, dpp_f64_rm<0x143, 0xc>(mx)); mn = vmin64(mn, dpp_f64_rm<0x143, 0xc>(mn));   // row_bcast31 -> rows 2,3
+  mx = readlane_f64(mx, 63);
+  mn = readlane_f64(mn, 63);
 }
 
-// tnorm from the pre-generated record of the call: R[4k+0..3] = ua, log ua, log ub, Box-Muller
-// normal of attempt k; R[16] = fallback uniform.  Same decisions and values as bl::tnorm.
-__device__ inline double tnorm_pre(const double* __restrict__ R, double lo, double hi)
+// tnorm from the pre-generated record of the call, attempts evaluated by lanes 0..3 at once.
+// Lane g < 5 holds group g of the record: g < 4: (ua, log ua, log ub, Box-Muller normal) of
+// attempt g; g = 4: (fallback uniform, -, -, -).  lo/hi are wave-uniform.  The first accepted
+// attempt in attempt order wins, else the exact inverse-CDF draw: same decisions and values as
+// bl::tnorm on the same nine uniforms.
+__device__ __forceinline__ double tnorm_lanes(double r0, double r1, double r2, double r3, int lane, double lo, double hi)
 {
   const bool lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return qnorm(R[16]);
+  if (lo_inf && hi_inf) return qnorm(readlane_f64(r0, 4));
   if (!(hi - lo > 0.0)) return lo;
+  double x;
+  bool ok;
+  bool flip = false;
+  double a = lo, b = hi;
   if (lo <= 0.0 && hi >= 0.0) {
-    const bool wide = hi - lo > 2.5066282746310002;
-    for (int k = 0; k < 4; ++k) {
-      if (wide) {
-        const double x = R[4 * k + 3];
-        if (x >= lo && x <= hi) return x;
-      } else {
-        const double x = lo + (hi - lo) * R[4 * k];
-        if (R[4 * k + 2] <= -0.5 * x * x) return x;
-      }
+    if (hi - lo > 2.5066282746310002) {
+      x = r3;
+      ok = x >= lo && x <= hi;
+    } else {
+      x = lo + (hi - lo) * r0;
+      ok = r2 <= -0.5 * x * x;
     }
+  } else {
+    flip = hi < 0.0;
+    a = flip ? -hi : lo;
+    b = flip ? -lo : hi;
+    const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
+    if (b - a > 1.0 / alpha) {
+      x = a - r1 / alpha;
+      const double d = x - alpha;
+      ok = x <= b && r2 <= -0.5 * d * d;
+    } else {
+      x = a + (b - a) * r0;
+      ok = r2 <= 0.5 * (a * a - x * x);
+    }
+  }
+  const uint64_t m = __ballot(ok && lane < 4);
+  if (m != 0) {
+    const int first = __builtin_ctzll(m);
+    x = readlane_f64(x, first);
+    return flip ? -x : x;
+  }
+  const double u8 = readlane_f64(r0, 4);
+  if (lo <= 0.0 && hi >= 0.0) {
     const double pl = lo_inf ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
     const double ph = hi_inf ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
-    double x = qnorm(pl + R[16] * (ph - pl));
-    x = x < lo ? lo : x;
-    x = x > hi ? hi : x;
-    return x;
+    double xi = qnorm(pl + u8 * (ph - pl));
+    xi = xi < lo ? lo : xi;
+    xi = xi > hi ? hi : xi;
+    return xi;
   }
-  const bool flip = hi < 0.0;
-  const double a = flip ? -hi : lo, b = flip ? -lo : hi;
-  const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
-  const bool tail = b - a > 1.0 / alpha;
-  double x = a;
-  bool done = false;
-  for (int k = 0; k < 4 && !done; ++k) {
-    if (tail) {
-      x = a - R[4 * k + 1] / alpha;
-      const double d = x - alpha;
-      done = x <= b && R[4 * k + 2] <= -0.5 * d * d;
-    } else {
-      x = a + (b - a) * R[4 * k];
-      done = R[4 * k + 2] <= 0.5 * (a * a - x * x);
-    }
-  }
-  if (!done) x = tnorm_inv_right(a, b, R[16]);
+  x = tnorm_inv_right(a, b, u8);
   return flip ? -x : x;
 }
 
@@ -910,7 +945,7 @@ __device__ void lds_solve_L(const double* Lm, double* b, int P, int ld)
   }
 }
 
-constexpr int kRec = 17;   // doubles per pre-generated tnorm record
+constexpr int kRec = 20;   // doubles per pre-generated tnorm record: 4 attempts x (ua, log ua, log ub, normal) + (u8,0,0,0)
 
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
@@ -922,12 +957,14 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double* mP = Ri + P * ld;
   double* zz = mP + P;
   int* perm = reinterpret_cast<int*>(zz + P);       // P ints
+  int* ptab = perm + P + (P & 1);                    // ptab[k][i]: coordinate visited at step i of scan k (P*P ints)
+  double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
   int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);   // P*(P-1) swap targets
   int* sig = swp + P * P;                            // sig[k][.]: scan k's swaps applied to the identity
-  int* ptab = sig + P * P;                           // ptab[k][i]: coordinate visited at step i of scan k
   __shared__ int bad;
   if (t == 0) bad = 0;
+  if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
   for (int e = t; e < P * P; e += kBlock) {
     const int i = e % P, j = e / P;
     L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
@@ -956,8 +993,10 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
       }
       R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+      R[17] = R[18] = R[19] = 0.0;
     }
   }
+  if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
   __syncthreads();
   if (mode == blk::B_CONSTRAINED) {
     // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel ...
@@ -979,6 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     }
   }
 
+  if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
   if (!lds_chol_upper(A, P, ld, &bad)) {
     __syncthreads();
     if (t == 0) atomicOr(a.status, 8);
@@ -1005,6 +1045,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     return;
   }
 
+  if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
   for (int e = t; e < P * P; e += kBlock) {
     const int i = e % P, j = e / P;
     L_(S, i, j) = (i == j) ? 1.0 : 0.0;
@@ -1012,6 +1053,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   __syncthreads();
   lds_solve_Ut(A, S, P, ld, P, ld);
   lds_solve_U(A, S, P, ld, P, ld);
+  if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
 
   if (mode == blk::B_FROM_LIK) {
     for (int i = t; i < P; i += kBlock) {
@@ -1056,32 +1098,64 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   __syncthreads();
   lds_solve_L(S, zz, P, ld);
 
-  if (t < 64) {
-    const int lane = t;
-    const bool row = lane < P;
-    double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j
-    double zj = row ? zz[lane] : 0.0;                // z_j
-    const double inf = __builtin_huge_val();
-    for (int k = 0; k < P; ++k) {
+  if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
+  // The serial coordinate sweeps run on wave 0; waves 1-3 stage the next scan's random records
+  // from global scratch into LDS meanwhile (one barrier per scan), so a step reads only LDS.
+  const int lane = t & 63;
+  const bool serial = t < 64;
+  const bool row = serial && lane < P;
+  double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j
+  double zj = row ? zz[lane] : 0.0;                // z_j
+  const double inf = __builtin_huge_val();
+  const int nrec = P * kRec;
+  for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
+  __syncthreads();
+  for (int k = 0; k < P; ++k) {
+    const double* Rk = recL + (k & 1) * nrec;
+    if (!serial) {
+      if (k + 1 < P) {
+        double* Rn = recL + ((k + 1) & 1) * nrec;
+        const double* src = rec + (size_t)(k + 1) * nrec;
+        for (int e = t - 64; e < nrec; e += kBlock - 64) Rn[e] = src[e];
+      }
+    } else {
+      // everything step i+1 needs that does not depend on step i is fetched while step i computes
+      const int g4 = (lane < 5 ? lane : 0) * 4;
+      int c_n = __builtin_amdgcn_readfirstlane(ptab[k * P]);
+      int c_nn = ptab[k * P + (P > 1 ? 1 : 0)];                    // two steps ahead (still a VGPR)
+      double l1_n = row ? L_(S, lane, c_n) : 0.0, ri_n = row ? L_(Ri, lane, c_n) : 0.0;
+      double q0 = Rk[g4], q1 = Rk[g4 + 1], q2 = Rk[g4 + 2], q3 = Rk[g4 + 3];
       for (int i = 0; i < P; ++i) {
-        const int c = __builtin_amdgcn_readfirstlane(ptab[k * P + i]);
-        const double* R = rec + ((size_t)k * P + i) * kRec;
+        const int c = c_n;
+        const double l1 = l1_n, ri = ri_n;
+        const double r0 = q0, r1 = q1, r2 = q2, r3 = q3;
+        if (i + 1 < P) {
+          c_n = __builtin_amdgcn_readfirstlane(c_nn);
+          c_nn = ptab[k * P + (i + 2 < P ? i + 2 : i + 1)];
+          l1_n = row ? L_(S, lane, c_n) : 0.0;
+          ri_n = row ? L_(Ri, lane, c_n) : 0.0;
+          const double* Rn = Rk + (i + 1) * kRec + g4;
+          q0 = Rn[0];
+          q1 = Rn[1];
+          q2 = Rn[2];
+          q3 = Rn[3];
+        }
         const double z1 = readlane_f64(zj, c);
-        const double l1 = row ? L_(S, lane, c) : 0.0;
-        const double ri = row ? L_(Ri, lane, c) : 0.0;
         const double c1 = z1 - bj * ri;
         const bool in = row && lane >= c && lane < P - 1;
         double lo = (in && l1 > 0.0) ? c1 : -inf;
         double hi = (in && l1 < 0.0) ? c1 : inf;
         wave_maxmin(lo, hi);
-        const double z2 = tnorm_pre(R, lo, hi);
+        const double z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
         const double dz = z2 - z1;
         if (row && lane >= c) bj += l1 * dz;
         if (lane == c) zj = z2;
       }
     }
-    if (row) a.beta_out[lane] = bj;
+    __syncthreads();
   }
+  if (row) a.beta_out[lane] = bj;
+  if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
 }
 #undef L_
 
@@ -1240,7 +1314,7 @@ void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_o
 size_t beta_work_doubles(int P)
 {
   const size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
-  const size_t small = (size_t)P * P * kRec + 3 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
+  const size_t small = (size_t)P * P * kRec + 2 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
   return generic > small ? generic : small;
 }
 
@@ -1248,7 +1322,8 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
 {
   if (a.P <= 64) {
     const int ld = a.P + 1;
-    const size_t lds = (3 * (size_t)a.P * ld + 2 * (size_t)a.P) * 8 + 2 * (size_t)a.P * 4 + 16;
+    const size_t lds = (3 * (size_t)a.P * ld + 2 * (size_t)a.P) * 8 + ((size_t)a.P + 1 + (size_t)a.P * a.P + 1) * 4 +
+                       2 * (size_t)a.P * kRec * 8 + 32;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_beta64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
