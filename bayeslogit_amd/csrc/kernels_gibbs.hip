@@ -275,23 +275,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
 // PP = sum over workgroups (fixed order) of the permuted MFMA blocks; un-permute,
 // take the i <= j half of diagonal blocks, mirror: PP is exactly symmetric.
 template <int NB>
-__global__ __launch_bounds__(kBlock) void k_reduce_fused(const double* __restrict__ partial, int nparts,
-                                                         double* __restrict__ PP)
+__global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict__ partial, int nparts,
+                                                       double* __restrict__ PP)
 {
   constexpr int P = 16 * NB;
   constexpr int NBLK = NB * (NB + 1) / 2;
   constexpr int E = NBLK * 4 * 64;
-  __shared__ double sm[4][64];
+  __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int s = threadIdx.x >> 6;
+  const int s = threadIdx.x >> 6;            // 16 waves: wave s sums slabs s, s+16, ... (fixed order)
   double sum = 0.0;
   if (e < E)
-    for (int b = s; b < nparts; b += 4) sum += partial[(size_t)b * E + e];
+    for (int b = s; b < nparts; b += 16) sum += partial[(size_t)b * E + e];
   sm[s][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s == 0 && e < E) {
     const int l = threadIdx.x & 63;
-    const double tot = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    double tot = sm[0][l];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tot += sm[q][l];
     const int blkid = e / 256, reg = (e >> 6) & 3, ln = e & 63;
     int qa = 0, qb = 0, id = 0;
     for (int a = 0; a < NB; ++a)
@@ -1209,7 +1211,7 @@ void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, co
     hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta, off,
                        w, N, seed, epoch, idx0, status);
   hipLaunchKernelGGL((k_xwx_mfma<NB>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, partial);
-  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(kBlock), 0, s, partial, plan.nblocks, PP);
+  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP);
 }
 
 }  // namespace

@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-gibbs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--mixed", action="store_true", help="also time config C3 (mixed shapes)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -56,7 +57,7 @@ def barrier_sync(world):
 def max_over_ranks(x, world, dev):
     if world == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
 
@@ -100,14 +101,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    devidx = (local % ndev) if world > 1 else 0       # local == device on a real multi-GPU node
+    dev = torch.device("cuda", devidx)
+    torch.cuda.set_device(dev)
     if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
     elif a.gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    dev = torch.device("cuda", local if world > 1 else 0)
-    torch.cuda.set_device(dev)
 
     from bayeslogit_amd import _lib
     from bayeslogit_amd import device as D
@@ -233,7 +238,7 @@ def main():
             "beta_draw": "constrained = the reference's active draw (Logit.hpp:322-400); "
                          "unconstrained = Logit.hpp:291-320",
             **res,
-            "roofline": {"kernel": "k_sweep_fused<4,0> (+ reduce)", "bound": "hbm", "achieved": gb,
+            "roofline": {"kernel": "k_psi_omega_nb<4,0> + k_xwx_mfma<4> + k_reduce_fused<4> (one sweep over X)", "bound": "hbm", "achieved": gb,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": sk, "algorithmic_bytes_per_launch": 8 * nl * P},
             "beta_mean_head": [float(v) for v in shard.get_beta()[:4]],

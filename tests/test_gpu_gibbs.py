@@ -241,3 +241,20 @@ def test_full_size_C4_properties(gpu):
     g.sweep_local(0, None)
     assert torch.equal(g.pp().reshape(P, P), PP)
     g.close()
+
+
+def test_dist_driver_with_hip_shard(gpu, oracle):
+    """bayeslogit_amd.dist.DistGibbs driving the real HIP shard (world size 1: the collectives are
+    no-ops, the sequencing and the library-owned P*P / P buffers exposed as torch tensors are real)."""
+    from bayeslogit_amd.dist import DistGibbs
+    X, y, n = synth(3000, 32, 77, nmax=2)
+    m0, P0 = np.full(32, 0.05), np.eye(32) * 0.3
+    for con in (0, 1):
+        sh = shard_of(X, y, n, gpu, seed=5)
+        drv = DistGibbs(sh)
+        drv.setup(m0, P0, np.zeros(32))
+        assert np.allclose(sh.bp().cpu().numpy(), oracle.set_bP(y, X, n, m0, P0), rtol=1e-11, atol=1e-12)
+        hist = drv.run(samp=4, burn=2, constrain=con).numpy()
+        _, ref = oracle.gibbs(y, X, n, m0, P0, samp=4, burn=2, seed=5, constrain=con, store_w=False)
+        assert np.allclose(hist, ref, rtol=1e-7, atol=1e-9), np.abs(hist - ref).max()
+        sh.close()
