@@ -14,6 +14,21 @@
 
 namespace bl {
 
+// a/b to ~1 ulp without the IEEE division sequence (v_div_scale/fmas/fixup): hardware
+// reciprocal estimate, two Newton steps, one correction.  b normal, no overflow handling.
+BL_HD double bl_div(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+#else
+  double r = 1.0 / b;
+#endif
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
 BL_HD double bl_log(double x)
 {
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -31,7 +46,7 @@ BL_HD double bl_log(double x)
   double m;
   memcpy(&m, &mb, 8);
   const double f = m - 1.0;
-  const double s = f / (2.0 + f);
+  const double s = bl_div(f, 2.0 + f);
   const double z = s * s;
   const double w = z * z;
   const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
@@ -46,9 +61,14 @@ BL_HD double bl_exp(double x)
 {
   constexpr double inv_ln2 = 1.44269504088896338700e+00;
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  if (x < -745.2) return 0.0;
+  if (x < -708.0) return 0.0;   // below: results would be subnormal; the samplers treat them as 0
   if (x > 709.78) return __builtin_huge_val();
-  const double kd = rint(x * inv_ln2);
+  // k = round(x / ln 2) by the 1.5 * 2^52 trick: the integer lands in the low mantissa bits
+  const double shifted = x * inv_ln2 + 0x1.8p52;
+  const double kd = shifted - 0x1.8p52;
+  uint64_t sb;
+  memcpy(&sb, &shifted, 8);
+  const int k = (int)(uint32_t)sb;
   const double r = (x - kd * ln2_hi) - kd * ln2_lo;
   // exp(r), |r| <= 0.3466: Taylor to r^13 (truncation 4e-18)
   double p = 1.0 / 6227020800.0;
@@ -65,7 +85,13 @@ BL_HD double bl_exp(double x)
   p = p * r + 0.5;
   p = p * r + 1.0;
   p = p * r + 1.0;
-  return ldexp(p, (int)kd);
+  // p in [0.70, 1.42]: scale by 2^k through the exponent field (result stays normal: x >= -708)
+  uint64_t pb;
+  memcpy(&pb, &p, 8);
+  pb += (uint64_t)(uint32_t)k << 52;   // wraps mod 2^64: correct for negative k
+  double out;
+  memcpy(&out, &pb, 8);
+  return out;
 }
 
 }  // namespace bl

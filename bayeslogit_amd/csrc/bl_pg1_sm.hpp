@@ -158,7 +158,10 @@ BL_HD void pg1_advance_g_inl(Pg1Lane& s, const Pg1Par& p, double u, double lu)
 // is then 0.25 * lane.X and the lane is back in SM_BRANCH for the next one.
 // FAST: bl_fastmath log/exp (default) or libm's; COLDG: large-|z| branch out of line or inline
 // (inline measured faster on gfx950 at 3 waves/SIMD: 8.6 vs 9.7 ms per 1e8 draws, z ~ U(0,4)).
-template <bool FAST = true, bool COLDG = false>
+// ZC: what the caller guarantees about the lane's observation -- 0 nothing, 1 |z|/2 < 1/t (the
+// mu > t inverse-Gaussian branch: states L_*), 2 |z|/2 >= 1/t (states G_*).  A wave whose lanes
+// all hold observations of one class compiles and executes only that class's states.
+template <bool FAST = true, bool COLDG = false, int ZC = 0>
 BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
 {
   const int st = s.st;
@@ -166,7 +169,7 @@ BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
   const double lu = FAST ? bl_log(u) : log(u);
   // the one division: E/fz (RIGHT_E, :171), t/(1+t E1)^2 (L_E2, :98-99), -4/X (ACCEPT, left piece)
   double num = -lu, den = p.fz;
-  if (st == SM_L_E2) {
+  if (ZC != 2 && st == SM_L_E2) {
     const double d = 1.0 + s.aux * kSmT;
     num = kSmT;
     den = d * d;
@@ -175,10 +178,10 @@ BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
     num = -4.0;
     den = s.X;
   }
-  const double q = num / den;
+  const double q = FAST ? bl_div(num, den) : num / den;
   double Xc = s.X;
   if (st == SM_RIGHT_E) Xc = kSmT + q;
-  if (st == SM_L_E2) Xc = q;
+  if (ZC != 2 && st == SM_L_E2) Xc = q;
   // the one exponential: alpha = exp(-Z^2 X/2) (L_E2, :100) or a_1/a_0 = 3 exp(.) (ACCEPT)
   double earg = -0.5 * p.Z * p.Z * Xc;
   if (st == SM_ACCEPT) earg = Xc > kSmT ? -kSmPiSq * Xc : q;
@@ -189,7 +192,7 @@ BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
     case SM_BRANCH:
       if (u < p.mass) {
         s.st = SM_RIGHT_E;
-      } else if (kSmTRecip > p.Z) {                                              // :87, mu > t
+      } else if (ZC == 1 || (ZC == 0 && kSmTRecip > p.Z)) {                      // :87, mu > t
         s.st = SM_L_TEST;
         s.aux = 0.0;                                                             // alpha = 0, :88
       } else {
@@ -201,22 +204,26 @@ BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
       s.st = SM_ACCEPT;
       break;
     case SM_L_TEST:                                                              // :89
-      s.st = (u > s.aux) ? SM_L_E1 : SM_ACCEPT;
+      if (ZC != 2) s.st = (u > s.aux) ? SM_L_E1 : SM_ACCEPT;
       break;
     case SM_L_E1:
-      s.aux = -lu;                                                               // E1
-      s.st = SM_L_E2;
-      break;
-    case SM_L_E2: {
-      const double E1 = s.aux, E2 = -lu;
-      if (E1 * E1 > 2.0 * E2 / kSmT) {                                           // :95
-        s.st = SM_L_E1;
-      } else {
-        s.X = Xc;
-        s.aux = ex;                                                              // alpha
-        s.st = SM_L_TEST;
+      if (ZC != 2) {
+        s.aux = -lu;                                                             // E1
+        s.st = SM_L_E2;
       }
-    } break;
+      break;
+    case SM_L_E2:
+      if (ZC != 2) {
+        const double E1 = s.aux, E2 = -lu;
+        if (E1 * E1 > 2.0 * E2 / kSmT) {                                         // :95
+          s.st = SM_L_E1;
+        } else {
+          s.X = Xc;
+          s.aux = ex;                                                            // alpha
+          s.st = SM_L_TEST;
+        }
+      }
+      break;
     case SM_ACCEPT: {
       // U a_0 <= a_0 - a_1  <=>  U <= 1 - a_1/a_0 ;  X <= 0 cannot occur (X > 0 always)
       bool ok = u <= 1.0 - 3.0 * ex;
@@ -231,8 +238,10 @@ BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
     case SM_G_N1:
     case SM_G_N2:
     case SM_G_U:
-      if (COLDG) pg1_advance_g(s, p, u, lu);
-      else pg1_advance_g_inl(s, p, u, lu);
+      if (ZC != 1) {
+        if (COLDG) pg1_advance_g(s, p, u, lu);
+        else pg1_advance_g_inl(s, p, u, lu);
+      }
       break;
     default: break;
   }

@@ -2,6 +2,7 @@
 // contract (DESIGN.md "RNG stream contract").  Portable (host + device).
 #pragma once
 #include "bl_portable.hpp"
+#include <string.h>
 
 namespace bl {
 
@@ -25,10 +26,15 @@ BL_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
   return U4{c0, c1, c2, c3};
 }
 
+// (m + 1/2) 2^-52 for the 52-bit integer m = (hi:lo) >> 12, built without an int->fp conversion:
+// 1.m (exponent 0 | mantissa m) minus 1 is m 2^-52 exactly, and adding 2^-53 is exact too
+// (2m+1 < 2^53), so this is bit-for-bit ((double)m + 0.5) * 2^-52.
 BL_HD double u52(uint32_t hi, uint32_t lo)
 {
-  const uint64_t m = (((uint64_t)hi << 32) | lo) >> 12;
-  return ((double)m + 0.5) * 0x1.0p-52;
+  const uint64_t bits = 0x3FF0000000000000ull | ((((uint64_t)hi << 32) | lo) >> 12);
+  double d;
+  memcpy(&d, &bits, 8);
+  return (d - 1.0) + 0x1.0p-53;
 }
 
 // counter words 0..2 of stream (idx, domain, epoch); word 3 is the block number

@@ -15,21 +15,86 @@ constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride
 // ---------------------------------------------------------------- rpg_devroye
 // Wavefront work queue.  Each wave owns chunks of kChunk consecutive observations.
 //   phase 1 (all 64 lanes busy): coalesced load of z, proposal mass of every observation of
-//            the chunk (pg1_par: two Chebyshev sums), staged in LDS;
-//   phase 2: the lane-uniform state machine of bl_pg1_sm.hpp.  A lane whose draw has
-//            completed takes the next unstarted observation of the chunk: idle lanes are found
-//            with __ballot and numbered with a prefix popcount, so the wave keeps all lanes on
-//            the same transition body instead of waiting for its slowest rejection loop.
-// The stream belongs to the observation, so which lane draws it does not change the result.
-constexpr int kChunk = 512;
+//            the chunk (pg1_par: two Chebyshev sums) staged in LDS (z itself is re-read from L2
+//            when a lane starts the observation), and the observations
+//            COMPACTED BY CLASS into two index lists (ballot + prefix popcount): |z|/2 < 1/t
+//            and |z|/2 >= 1/t take different left-piece samplers (PolyaGamma.cpp:87 vs :103),
+//            i.e. different states of the machine;
+//   phase 2: once per class, the lane-uniform state machine of bl_pg1_sm.hpp compiled for that
+//            class only.  A lane whose draw has completed takes the next unstarted observation
+//            of the list (idle lanes found with __ballot, numbered with a prefix popcount), so
+//            the wave keeps all lanes on the same short transition body instead of waiting for
+//            its slowest rejection loop or executing another class's code.
+// The stream belongs to the observation, so which lane draws it, and when, does not change the
+// result.
+constexpr int kChunk = 1024;   // 16 observations per lane: the queue's drain tail is ~8% of a chunk
+
+template <int ZC>
+__device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__ list, int cnt,
+                                              const double* __restrict__ z, const double* __restrict__ sM,
+                                              double* __restrict__ x, const int* __restrict__ nvec, int nscalar,
+                                              int64_t base, uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
+                                              uint64_t lt_mask, int& st_flags)
+{
+  int next = 0;      // wave-uniform: first unstarted entry of the list
+  int q = -1;        // this lane's observation (slot in the chunk), -1 = idle
+  int nrem = 0;
+  uint32_t c0 = 0, c1 = 0, blk = 0;
+  double sum = 0.0;
+  Pg1Par par{0.0, 1.0, 0.5};
+  Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
+  for (;;) {
+    const bool idle = q < 0;
+    const uint64_t im = __ballot(idle);
+    if (im != 0 && next < cnt) {
+      const int cand = next + __popcll(im & lt_mask);
+      if (idle && cand < cnt) {
+        const int slot = list[cand];
+        int n = nvec ? nvec[base + slot] : nscalar;
+        if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }       // PolyaGamma.cpp:128-135 (NTHROW)
+        q = slot;
+        nrem = n;
+        par.Z = fabs(z[base + slot]) * 0.5;          // re-read (L2): only the mass is staged in LDS
+        par.mass = sM[slot];
+        par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
+        const uint64_t idx = idx0 + (uint64_t)(base + slot);
+        c0 = (uint32_t)idx;
+        c1 = ctr1_of(idx, DOM_DRAW);
+        blk = 0;
+        sum = 0.0;
+        sm.st = SM_BRANCH;
+      }
+      next += __popcll(im);
+    }
+    if (__ballot(q >= 0) == 0) {
+      if (next >= cnt) break;
+      continue;
+    }
+    if (q >= 0) {
+      const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
+      blk += 1;
+      double u = u52(o.x, o.y);
+      const double u_second = u52(o.z, o.w);
+#pragma unroll 1
+      for (int half = 0; half < 2 && q >= 0; ++half) {
+        if (pg1_advance<true, false, ZC>(sm, par, u, st_flags)) {
+          sum += 0.25 * sm.X;
+          if (--nrem == 0) { x[base + q] = sum; q = -1; }
+        }
+        u = u_second;
+      }
+      if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
+    }
+  }
+}
 
 __global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
-                                                        int nscalar, const double* __restrict__ z, int64_t num,
-                                                        uint64_t seed, uint32_t epoch, uint64_t idx0,
-                                                        int* __restrict__ status)
+                                                           int nscalar, const double* __restrict__ z, int64_t num,
+                                                           uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                           int* __restrict__ status)
 {
-  __shared__ double sZ[kBlock / 64][kChunk];
   __shared__ double sM[kBlock / 64][kChunk];
+  __shared__ unsigned short sIdx[kBlock / 64][kChunk];   // class 1 from the front, class 2 from the back
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -38,67 +103,34 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ 
   for (int64_t ch = (int64_t)blockIdx.x * (kBlock / 64) + wave; ch < nchunks; ch += (int64_t)gridDim.x * (kBlock / 64)) {
     const int64_t base = ch * kChunk;
     const int cnt = (int)((num - base) < kChunk ? (num - base) : kChunk);
-    for (int k = lane; k < cnt; k += 64) {
-      const Pg1Par p = pg1_par(z[base + k]);
-      sZ[wave][k] = p.Z;
-      sM[wave][k] = p.mass;
+    int nA = 0, nB = 0;   // wave-uniform list lengths
+    for (int k0s = 0; k0s < cnt; k0s += 64) {
+      const int k = k0s + lane;
+      bool small = false, large = false;
+      if (k < cnt) {
+        const int n = nvec ? nvec[base + k] : nscalar;
+        if (n == 0) {
+          x[base + k] = 0.0;                         // LogitWrapper.cpp:74-77
+        } else {
+          const Pg1Par p = pg1_par(z[base + k]);
+          sM[wave][k] = p.mass;
+          small = kSmTRecip > p.Z;                   // PolyaGamma.cpp:87
+          large = !small;
+        }
+      }
+      const uint64_t ma = __ballot(small), mb = __ballot(large);
+      if (small) sIdx[wave][nA + __popcll(ma & lt_mask)] = (unsigned short)k;
+      if (large) sIdx[wave][kChunk - 1 - (nB + __popcll(mb & lt_mask))] = (unsigned short)k;
+      nA += __popcll(ma);
+      nB += __popcll(mb);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    int next = 0;      // wave-uniform: first unstarted observation of the chunk
-    int q = -1;        // this lane's observation (slot in the chunk), -1 = idle
-    int nrem = 0;
-    uint32_t c0 = 0, c1 = 0, blk = 0;
-    double sum = 0.0;
-    Pg1Par par{0.0, 1.0, 0.5};
-    Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
-    for (;;) {
-      const bool idle = q < 0;
-      const uint64_t im = __ballot(idle);
-      if (im != 0 && next < cnt) {
-        const int cand = next + __popcll(im & lt_mask);
-        if (idle && cand < cnt) {
-          int n = nvec ? nvec[base + cand] : nscalar;
-          if (n == 0) {
-            x[base + cand] = 0.0;                 // LogitWrapper.cpp:74-77
-          } else {
-            if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }
-            q = cand;
-            nrem = n;
-            par.Z = sZ[wave][cand];
-            par.mass = sM[wave][cand];
-            par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
-            const uint64_t idx = idx0 + (uint64_t)(base + cand);
-            c0 = (uint32_t)idx;
-            c1 = ctr1_of(idx, DOM_DRAW);
-            blk = 0;
-            sum = 0.0;
-            sm.st = SM_BRANCH;
-          }
-        }
-        next += __popcll(im);
-      }
-      if (__ballot(q >= 0) == 0) {
-        if (next >= cnt) break;
-        continue;
-      }
-      if (q >= 0) {
-        const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
-        blk += 1;
-        double u = u52(o.x, o.y);
-        const double u_second = u52(o.z, o.w);
-#pragma unroll 1
-        for (int half = 0; half < 2 && q >= 0; ++half) {
-          if (pg1_advance(sm, par, u, st_flags)) {
-            sum += 0.25 * sm.X;
-            if (--nrem == 0) { x[base + q] = sum; q = -1; }
-          }
-          u = u_second;
-        }
-        if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
-      }
-    }
+    if (nA > 0)
+      devroye_queue<1>(&sIdx[wave][0], nA, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+    if (nB > 0)
+      devroye_queue<2>(&sIdx[wave][kChunk - nB], nB, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask,
+                       st_flags);
     __builtin_amdgcn_wave_barrier();
   }
   if (st_flags) atomicOr(status, st_flags);
