@@ -197,7 +197,6 @@ __device__ inline double tnorm_inv_right(double a, double b, double u)
 __device__ inline double tnorm_from_uniforms(const double* U, double lo, double hi)
 {
   const bool lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return qnorm(U[8]);
   if (!(hi - lo > 0.0)) return lo;
   if (lo <= 0.0 && hi >= 0.0) {
     const bool wide = hi - lo > 2.5066282746310002;

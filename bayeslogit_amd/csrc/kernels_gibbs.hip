@@ -781,12 +781,19 @@ __device__ __forceinline__ double dpp_f64_rm(double v)
 // of 16 lanes (4 DPP levels), then row_bcast15 / row_bcast31 fold the four rows into row 3.
 // (A float-key fast path -- one VOP2-DPP op per level, winner located by ballot -- was tried and
 // measured slower: its VALU->SGPR->branch crossings cost more than the 64-bit moves they save.)
+template <int CTRL>
+__device__ __forceinline__ double dppmov_f64(double v)      // every lane has a valid source: no `old` copy
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
 {
-  mx = vmax64(mx, dpp_f64<0xB1>(mx));  mn = vmin64(mn, dpp_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
-  mx = vmax64(mx, dpp_f64<0x4E>(mx));  mn = vmin64(mn, dpp_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
-  mx = vmax64(mx, dpp_f64<0x141>(mx)); mn = vmin64(mn, dpp_f64<0x141>(mn));   // row_half_mirror
-  mx = vmax64(mx, dpp_f64<0x140>(mx)); mn = vmin64(mn, dpp_f64<0x140>(mn));   // row_mirror
+  mx = vmax64(mx, dppmov_f64<0xB1>(mx));  mn = vmin64(mn, dppmov_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
+  mx = vmax64(mx, dppmov_f64<0x4E>(mx));  mn = vmin64(mn, dppmov_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
+  mx = vmax64(mx, dppmov_f64<0x141>(mx)); mn = vmin64(mn, dppmov_f64<0x141>(mn));   // row_half_mirror
+  mx = vmax64(mx, dppmov_f64<0x140>(mx)); mn = vmin64(mn, dppmov_f64<0x140>(mn));   // row_mirror
   mx = vmax64(mx, dpp_f64_rm<0x142, 0xa>(mx)); mn = vmin64(mn, dpp_f64_rm<0x142, 0xa>(mn));   // row_bcast15 -> rows 1,3
   mx = vmax64(mx, dpp_f64_rm<0x143, 0xc>(mx)); mn = vmin64(mn, dpp_f64_rm<0x143, 0xc>(mn));   // row_bcast31 -> rows 2,3
   mx = readlane_f64(mx, 63);
@@ -800,8 +807,6 @@ __device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
 // bl::tnorm on the same nine uniforms.
 __device__ __forceinline__ double tnorm_lanes(double r0, double r1, double r2, double r3, int lane, double lo, double hi)
 {
-  const bool lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return qnorm(readlane_f64(r0, 4));
   if (!(hi - lo > 0.0)) return lo;
   double x;
   bool ok;
@@ -837,8 +842,8 @@ __device__ __forceinline__ double tnorm_lanes(double r0, double r1, double r2, d
   }
   const double u8 = readlane_f64(r0, 4);
   if (lo <= 0.0 && hi >= 0.0) {
-    const double pl = lo_inf ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
-    const double ph = hi_inf ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
+    const double pl = isinf(lo) ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
+    const double ph = isinf(hi) ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
     double xi = qnorm(pl + u8 * (ph - pl));
     xi = xi < lo ? lo : xi;
     xi = xi > hi ? hi : xi;

@@ -226,8 +226,8 @@ double bl_tnorm(bl_rng *r, double lo, double hi)
   double U[9];
   for (int k = 0; k < 9; ++k) U[k] = bl_unif(r);
   int lo_inf = isinf(lo) && lo < 0, hi_inf = isinf(hi) && hi > 0;
-  if (lo_inf && hi_inf) return bl_qnorm(U[8]);
   if (!(hi - lo > 0.0)) return lo;                      /* empty / degenerate / NaN */
+  /* (-inf, +inf) needs no special case: it is "wide", and its first Box-Muller attempt accepts */
   if (lo <= 0.0 && hi >= 0.0) {
     /* interval contains the mode */
     int wide = hi - lo > 2.5066282746310002;            /* sqrt(2 pi); true for infinite bounds */
