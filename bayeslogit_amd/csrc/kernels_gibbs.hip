@@ -954,6 +954,161 @@ __device__ void lds_solve_L(const double* Lm, double* b, int P, int ld)
 
 constexpr int kRec = 20;   // doubles per pre-generated tnorm record: 4 attempts x (ua, log ua, log ub, normal) + (u8,0,0,0)
 
+// ---- single-wavefront dense kernels on LDS matrices (P <= 64, lane = column or row) ----
+// One wave needs no s_barrier: LDS operations of a wave execute in program order, so a
+// wave-level scheduling fence between a phase's writes and the next phase's reads is enough.
+// The workgroup versions above pay two or three barriers per column (~1.4 us per column
+// measured); these run a 64x64 factorisation in ~15-20 us, and leave the other three waves free
+// to generate the draw's random input at the same time.
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+__device__ __forceinline__ double bcast_f64(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// A = U'U in place (upper triangle holds U); lane j owns column j.  Same operation order per
+// element as the reference's LAPACK-style column Cholesky (subtractions in ascending k).  The
+// pivot row is passed between lanes by readlane, so the trailing update touches LDS only for the
+// lane's own column (independent addresses: the loads of several rows are in flight together).
+__device__ bool w_chol_upper(double* A, int P, int ld, int lane)
+{
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(A, k, k);
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    double ukj = 0.0;
+    if (lane > k && lane < P) {
+      ukj = L_(A, k, lane) / d;
+      L_(A, k, lane) = ukj;
+    }
+    if (lane == k) L_(A, k, k) = d;
+    double* col = A + lane * ld;
+    int i = k + 1;
+    for (; i + 3 < P; i += 4) {
+      const double u0 = bcast_f64(ukj, i), u1 = bcast_f64(ukj, i + 1), u2 = bcast_f64(ukj, i + 2), u3 = bcast_f64(ukj, i + 3);
+      if (lane < P) {
+        const double a0 = col[i], a1 = col[i + 1], a2 = col[i + 2], a3 = col[i + 3];
+        if (lane >= i) col[i] = a0 - u0 * ukj;
+        if (lane >= i + 1) col[i + 1] = a1 - u1 * ukj;
+        if (lane >= i + 2) col[i + 2] = a2 - u2 * ukj;
+        if (lane >= i + 3) col[i + 3] = a3 - u3 * ukj;
+      }
+    }
+    for (; i < P; ++i) {
+      const double u0 = bcast_f64(ukj, i);
+      if (lane >= i && lane < P) col[i] -= u0 * ukj;
+    }
+    WAVE_SYNC();
+  }
+  return true;
+}
+
+// S = L L' in place (lower triangle holds L, strict upper zeroed); lane i owns row i.
+__device__ bool w_chol_lower(double* S, int P, int ld, int lane)
+{
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(S, k, k);
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    double lik = 0.0;
+    if (lane > k && lane < P) {
+      lik = L_(S, lane, k) / d;
+      L_(S, lane, k) = lik;
+    }
+    if (lane == k) L_(S, k, k) = d;
+    int j = k + 1;
+    for (; j + 3 < P; j += 4) {
+      const double l0 = bcast_f64(lik, j), l1 = bcast_f64(lik, j + 1), l2 = bcast_f64(lik, j + 2), l3 = bcast_f64(lik, j + 3);
+      if (lane < P) {
+        const double a0 = L_(S, lane, j), a1 = L_(S, lane, j + 1), a2 = L_(S, lane, j + 2), a3 = L_(S, lane, j + 3);
+        if (lane >= j) L_(S, lane, j) = a0 - lik * l0;
+        if (lane >= j + 1) L_(S, lane, j + 1) = a1 - lik * l1;
+        if (lane >= j + 2) L_(S, lane, j + 2) = a2 - lik * l2;
+        if (lane >= j + 3) L_(S, lane, j + 3) = a3 - lik * l3;
+      }
+    }
+    for (; j < P; ++j) {
+      const double l0 = bcast_f64(lik, j);
+      if (lane >= j && lane < P) L_(S, lane, j) -= lik * l0;
+    }
+    WAVE_SYNC();
+  }
+  for (int j = 1; j < P; ++j)
+    if (lane < j && lane < P) L_(S, lane, j) = 0.0;
+  WAVE_SYNC();
+  return true;
+}
+
+// S <- PP^{-1} given U (PP = U'U): S starts as I; lane c solves U'y = e_c then U x = y on its own
+// column of S (dot-product form, ascending k as the reference's trsm), four products in flight.
+__device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int lane)
+{
+  const int c = lane < P ? lane : 0;
+  double* col = S + c * ld;
+  for (int i = 0; i < P; ++i) {                            // forward: U' y = e_c
+    const double* ui = U + i * ld;                         // column i of U: U[k][i], k < i
+    double acc = col[i];
+    int k = 0;
+    for (; k + 3 < i; k += 4) {
+      const double p0 = ui[k] * col[k], p1 = ui[k + 1] * col[k + 1], p2 = ui[k + 2] * col[k + 2], p3 = ui[k + 3] * col[k + 3];
+      acc = (((acc - p0) - p1) - p2) - p3;
+    }
+    for (; k < i; ++k) acc -= ui[k] * col[k];
+    const double y = acc / ui[i];
+    if (lane < P) col[i] = y;
+  }
+  for (int i = P - 1; i >= 0; --i) {                       // backward: U x = y
+    double acc = col[i];
+    int k = i + 1;
+    for (; k + 3 < P; k += 4) {
+      const double p0 = L_(U, i, k) * col[k], p1 = L_(U, i, k + 1) * col[k + 1], p2 = L_(U, i, k + 2) * col[k + 2],
+                   p3 = L_(U, i, k + 3) * col[k + 3];
+      acc = (((acc - p0) - p1) - p2) - p3;
+    }
+    for (; k < P; ++k) acc -= L_(U, i, k) * col[k];
+    const double x = acc / L_(U, i, i);
+    if (lane < P) col[i] = x;
+  }
+  WAVE_SYNC();
+}
+
+// b <- U'^{-1} b, b_j in lane j's register
+__device__ double w_solve_Ut_vec(const double* U, double b, int P, int ld, int lane)
+{
+  for (int i = 0; i < P; ++i) {
+    const double bi = bcast_f64(b, i) / L_(U, i, i);
+    if (lane == i) b = bi;
+    if (lane > i && lane < P) b -= L_(U, i, lane) * bi;
+  }
+  return b;
+}
+// b <- U^{-1} b
+__device__ double w_solve_U_vec(const double* U, double b, int P, int ld, int lane)
+{
+  for (int i = P - 1; i >= 0; --i) {
+    const double bi = bcast_f64(b, i) / L_(U, i, i);
+    if (lane == i) b = bi;
+    if (lane < i) b -= L_(U, lane, i) * bi;
+  }
+  return b;
+}
+// b <- L^{-1} b (L lower)
+__device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int lane)
+{
+  for (int i = 0; i < P; ++i) {
+    const double bi = bcast_f64(b, i) / L_(Lm, i, i);
+    if (lane == i) b = bi;
+    if (lane > i && lane < P) b -= L_(Lm, lane, i) * bi;
+  }
+  return b;
+}
+
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];
@@ -968,75 +1123,29 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
   int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);   // P*(P-1) swap targets
-  int* sig = swp + P * P;                            // sig[k][.]: scan k's swaps applied to the identity
   __shared__ int bad;
   if (t == 0) bad = 0;
   if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
+  const bool need_inverse = mode == blk::B_CONSTRAINED || mode == blk::B_FROM_LIK;
   for (int e = t; e < P * P; e += kBlock) {
     const int i = e % P, j = e / P;
     L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
+    if (need_inverse) L_(S, i, j) = (i == j) ? 1.0 : 0.0;
   }
-
-  if (mode == blk::B_CONSTRAINED) {
-    // ---- all random input of the draw, in stream order (stream contract, DESIGN.md section 2: per scan k:
-    //      P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms each) ----
-    const uint32_t per_scan = (uint32_t)(10 * P - 1);
-    for (int e = t; e < P * (P - 1); e += kBlock) {
-      const int k = e / (P - 1), i = e % (P - 1);
-      const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
-      swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P), Logit.hpp:375
-    }
-    for (int e = t; e < P * P; e += kBlock) {
-      const int k = e / P, i = e % P;
-      const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
-      double* R = rec + (size_t)e * kRec;
-      for (int m = 0; m < 4; ++m) {
-        const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
-        const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
-        const double lua = log(ua);
-        R[4 * m] = ua;
-        R[4 * m + 1] = lua;
-        R[4 * m + 2] = log(ub);
-        R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
-      }
-      R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
-      R[17] = R[18] = R[19] = 0.0;
-    }
-  }
-  if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
   __syncthreads();
-  if (mode == blk::B_CONSTRAINED) {
-    // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel ...
-    if (t < P) {
-      int* sg = sig + t * P;
-      for (int i = 0; i < P; ++i) sg[i] = i;
-      for (int i = 0; i < P - 1; ++i) {
-        const int j = swp[t * (P - 1) + i];
-        const int tmp = sg[i];
-        sg[i] = sg[j];
-        sg[j] = tmp;
-      }
-    }
-    __syncthreads();
-    // ... then composed in scan order: `is` persists across scans (Logit.hpp:368-377)
-    for (int k = 0; k < P; ++k) {
-      if (t < P) ptab[k * P + t] = (k == 0) ? sig[t] : ptab[(k - 1) * P + sig[k * P + t]];
-      __syncthreads();
-    }
-  }
-
-  if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
-  if (!lds_chol_upper(A, P, ld, &bad)) {
-    __syncthreads();
-    if (t == 0) atomicOr(a.status, 8);
-    return;
-  }
 
   if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
+    // nothing to overlap with: the whole workgroup factors and solves (measured 0.136 ms vs 0.161 ms
+    // for the single-wave routines below)
+    if (!lds_chol_upper(A, P, ld, &bad)) {
+      __syncthreads();
+      if (t == 0) atomicOr(a.status, 8);
+      return;
+    }
     for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
     if (mode == blk::B_MVN)
       for (int i = t; i < P; i += kBlock) {
-        // eps_i = r.norm(0,1) in stream order: normal i is exactly Philox block i
+        // eps_i = r.norm(0,1) in stream order: normal i is exactly Philox block i     (Logit.hpp:311)
         const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * i), u2 = beta_stream_unif(a.seed, a.epoch, 2 * i + 1);
         zz[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
       }
@@ -1052,60 +1161,108 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     return;
   }
 
-  if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
-  for (int e = t; e < P * P; e += kBlock) {
-    const int i = e % P, j = e / P;
-    L_(S, i, j) = (i == j) ? 1.0 : 0.0;
+  if (t < 64) {
+    // ================= wave 0: the dense stage, alone, no workgroup barriers =================
+    const int lane = t;
+    bool ok = w_chol_upper(A, P, ld, lane);                                   // U = chol(PP,'U')
+    if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
+    if (ok && need_inverse) {
+      w_inverse_from_U(A, S, P, ld, lane);                                     // S = PP^{-1}
+      if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
+      if (mode == blk::B_FROM_LIK) {
+        // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps               (Normal.hpp:98-131)
+        double mean = 0.0, e = 0.0;
+        if (lane < P) {
+          for (int k2 = 0; k2 < P; ++k2) mean += L_(S, lane, k2) * a.bP[k2];
+          const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * lane), u2 = beta_stream_unif(a.seed, a.epoch, 2 * lane + 1);
+          e = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+          zz[lane] = e;
+        }
+        WAVE_SYNC();
+        ok = w_chol_lower(S, P, ld, lane);
+        if (ok && lane < P) {
+          double le = 0.0;
+          for (int k2 = 0; k2 <= lane; ++k2) le += L_(S, lane, k2) * zz[k2];
+          a.beta_out[lane] = le + mean;
+        }
+      } else {
+        // B_CONSTRAINED set-up, Logit.hpp:335-366
+        double m = lane < P ? a.bP[lane] : 0.0;
+        m = w_solve_Ut_vec(A, m, P, ld, lane);
+        m = w_solve_U_vec(A, m, P, ld, lane);                                 // mP
+        ok = w_chol_lower(S, P, ld, lane);                                    // L = chol(S,'L')
+        if (ok) {
+          for (int j = 0; j < P; ++j)
+            if (lane < P) L_(Ri, lane, j) = 1.0 / L_(S, lane, j);
+          double z = lane < P ? a.beta_prev[lane] - m : 0.0;                 // z = L^{-1}(beta_prev - mP)
+          z = w_solve_L_vec(S, z, P, ld, lane);
+          if (lane < P) zz[lane] = z;
+        }
+      }
+    }
+    if (!ok && t == 0) bad = 1;
+  } else if (mode == blk::B_CONSTRAINED) {
+    // ====== waves 1-3, meanwhile: every random input of the draw, in stream order
+    // (per scan k, P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms) ======
+    const int tt = t - 64, nt = kBlock - 64;
+    const uint32_t per_scan = (uint32_t)(10 * P - 1);
+    for (int e = tt; e < P * (P - 1); e += nt) {
+      const int k = e / (P - 1), i = e % (P - 1);
+      const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
+      swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P), Logit.hpp:375
+    }
+    for (int e = tt; e < P * P; e += nt) {
+      const int k = e / P, i = e % P;
+      const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+      double* R = rec + (size_t)e * kRec;
+      for (int m = 0; m < 4; ++m) {
+        const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+        const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+        const double lua = log(ua);
+        R[4 * m] = ua;
+        R[4 * m + 1] = lua;
+        R[4 * m + 2] = log(ub);
+        R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+      }
+      R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+      R[17] = R[18] = R[19] = 0.0;
+    }
+    // swap targets are read back by wave 1 only: make its own and its neighbours' stores visible
+    __threadfence_block();
+    // named barrier among waves 1-3 is not available: scan permutations are built after the
+    // workgroup barrier below instead (they are cheap: LDS only)
   }
+  if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
   __syncthreads();
-  lds_solve_Ut(A, S, P, ld, P, ld);
-  lds_solve_U(A, S, P, ld, P, ld);
-  if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
-
-  if (mode == blk::B_FROM_LIK) {
-    for (int i = t; i < P; i += kBlock) {
-      double s = 0.0;
-      for (int k2 = 0; k2 < P; ++k2) s += L_(S, i, k2) * a.bP[k2];
-      mP[i] = s;
-      const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * i), u2 = beta_stream_unif(a.seed, a.epoch, 2 * i + 1);
-      zz[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
-    }
-    __syncthreads();
-    if (!lds_chol_lower(S, P, ld, &bad)) {
-      __syncthreads();
-      if (t == 0) atomicOr(a.status, 8);
-      return;
-    }
-    for (int i = t; i < P; i += kBlock) {
-      double le = 0.0;
-      for (int k2 = 0; k2 <= i; ++k2) le += L_(S, i, k2) * zz[k2];
-      a.beta_out[i] = le + mP[i];
-    }
-    return;
-  }
-
-  // ---- B_CONSTRAINED, Logit.hpp:322-400 ----
-  for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
-  __syncthreads();
-  lds_solve_Ut(A, mP, P, ld, 1, P);
-  lds_solve_U(A, mP, P, ld, 1, P);
-  if (!lds_chol_lower(S, P, ld, &bad)) {
-    __syncthreads();
+  if (bad) {
     if (t == 0) atomicOr(a.status, 8);
     return;
   }
-  for (int e = t; e < P * P; e += kBlock) {
-    const int i = e % P, j = e / P;
-    L_(Ri, i, j) = 1.0 / L_(S, i, j);
-  }
-  for (int j = t; j < P; j += kBlock) {
-    zz[j] = a.beta_prev[j] - mP[j];
-    perm[j] = j;
+  if (mode != blk::B_CONSTRAINED) return;
+
+  // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel (thread k,
+  // its row of ptab in LDS as scratch), then composed in scan order: `is` persists across scans
+  // (Logit.hpp:368-377); the composition is in place, row by row.
+  if (t < P) {
+    int* sg = ptab + t * P;
+    for (int i = 0; i < P; ++i) sg[i] = i;
+    for (int i = 0; i < P - 1; ++i) {
+      const int j = swp[t * (P - 1) + i];
+      const int tmp = sg[i];
+      sg[i] = sg[j];
+      sg[j] = tmp;
+    }
   }
   __syncthreads();
-  lds_solve_L(S, zz, P, ld);
+  for (int k = 1; k < P; ++k) {
+    int v = 0;
+    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
+    __syncthreads();
+    if (t < P) ptab[k * P + t] = v;
+    __syncthreads();
+  }
 
-  if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
+  if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
   // The serial coordinate sweeps run on wave 0; waves 1-3 stage the next scan's random records
   // from global scratch into LDS meanwhile (one barrier per scan), so a step reads only LDS.
   const int lane = t & 63;
