@@ -16,7 +16,7 @@ enum WeightMode : int {
 // summation order -- and therefore every bit of PP -- is reproducible).
 struct SweepPlan {
   int P = 0;
-  int fused = 0;          // 1: MFMA path (P in {16,32,48,64}), 0: generic kernels
+  int fused = 0;          // 1: MFMA path, registers (P in {16,32,48,64}); 2: MFMA path, LDS tiles (P in {128,256}); 0: generic
   int nblocks = 0;        // workgroups of the X'WX kernel (= number of partial slabs)
   int nblocks_draw = 0;   // workgroups of the psi/omega kernel
   int nb = 0;             // fused: P/16

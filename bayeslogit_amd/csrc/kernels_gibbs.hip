@@ -50,7 +50,7 @@ __device__ __host__ __forceinline__ int colmap(int q, int c)
   if (NB == 1) return c;
   if (NB == 2) return 2 * c + q;
   if (NB == 3) return q < 2 ? 2 * c + q : 32 + c;
-  return (q >> 1) * 32 + 2 * c + (q & 1);
+  return (q >> 1) * 32 + 2 * c + (q & 1);        // NB even: block pair h = q>>1 covers columns 32h .. 32h+31
 }
 
 // One group = 4 consecutive rows; lane (k = lane>>4, c = lane&15) takes row k of the group and
@@ -63,18 +63,18 @@ __device__ __forceinline__ void load_group(double (&xg)[NB], const double* __res
   if (NB == 1) {
     const double v = p[c];
     xg[0] = ok ? v : 0.0;
-  } else {
+  } else if (NB == 3) {
     const v2d v0 = *reinterpret_cast<const v2d*>(p + 2 * c);
+    const double v = p[32 + c];
     xg[0] = ok ? v0.x : 0.0;
     xg[1] = ok ? v0.y : 0.0;
-    if (NB == 3) {
-      const double v = p[32 + c];
-      xg[2] = ok ? v : 0.0;
-    }
-    if (NB == 4) {
-      const v2d v1 = *reinterpret_cast<const v2d*>(p + 32 + 2 * c);
-      xg[2] = ok ? v1.x : 0.0;
-      xg[3] = ok ? v1.y : 0.0;
+    xg[2] = ok ? v : 0.0;
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      const v2d v = *reinterpret_cast<const v2d*>(p + 32 * h + 2 * c);
+      xg[2 * h] = ok ? v.x : 0.0;
+      xg[2 * h + 1] = ok ? v.y : 0.0;
     }
   }
 }
@@ -310,6 +310,143 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict_
   }
 }
 
+// ---- pass 2 for P = 128 / 256 (NB = 8 / 16): the rank-N update is compute-bound here
+// (N P^2 flops against 8 N P bytes: 10.4 ms of fp64 MFMA vs 3.2 ms of HBM per 25.6 GB shard at
+// P = 256), and the NB(NB+1)/2 accumulator blocks (136 at NB = 16) no longer fit one wave.  A
+// workgroup of NW waves (two per SIMD) shares 16-row tiles of X staged in LDS (row stride padded by
+// 128 B: the four rows of an MFMA operand land in disjoint bank halves) and splits the upper
+// triangle by block-row: wave w owns block-rows w and NB-1-w, i.e. exactly NB+1 blocks each, so it
+// loads two A fragments per 4-row group and one B fragment per MFMA.  Columns keep their natural
+// order here (block q = columns 16q..16q+15).
+template <int NB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_xwx_mfma_big(const double* __restrict__ tX,
+                                                             const double* __restrict__ w, int64_t N,
+                                                             double* __restrict__ partial)
+{
+  constexpr int P = 16 * NB;
+  constexpr int LDT = P + 16;                 // padded row stride (doubles)
+  constexpr int RT = 16;                      // rows per tile
+  constexpr int NT = NW * 64;
+  constexpr int VPT = RT * P / 2 / NT;        // 16-byte vectors per thread per tile
+  static_assert(NB % NW == 0 && (NB / NW == 1 || NB / NW == 2), "block-rows are dealt w and NB-1-w per wave");
+  extern __shared__ double lds[];
+  double* tile = lds;                         // [2][RT][LDT]
+  double* wt = lds + 2 * RT * LDT;            // [2][RT]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int k = lane >> 4, c = lane & 15;
+  const int64_t ntiles = (N + RT - 1) / RT;
+
+  v4d acc[NB + 1];
+#pragma unroll
+  for (int b = 0; b < NB + 1; ++b) acc[b] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  // NW == NB/2: wave w owns block-rows {w, NB-1-w}; NW == NB: pairs of waves would split a row --
+  // not needed for the instantiations built (NB = 8 with 4 waves, NB = 16 with 8 waves)
+  const int ra = wave, rb = NB - 1 - wave;    // the wave's two block-rows; ra has NB-ra blocks, rb has wave+1
+  const int na = NB - ra;
+
+  v2d stage[VPT];
+  double wstage = 0.0;
+  auto fetch = [&](int64_t tl) {
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int e = t + v * NT;                                    // vector index in the tile
+      const int r = e / (P / 2), cv = e % (P / 2);
+      const int64_t row = tl * RT + r;
+      stage[v] = row < N ? *reinterpret_cast<const v2d*>(tX + (size_t)row * P + 2 * cv) : v2d{0.0, 0.0};
+    }
+    if (t < RT) {
+      const int64_t row = tl * RT + t;
+      wstage = row < N ? w[row] : 0.0;
+    }
+  };
+  auto deposit = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int e = t + v * NT;
+      const int r = e / (P / 2), cv = e % (P / 2);
+      *reinterpret_cast<v2d*>(tile + (buf * RT + r) * LDT + 2 * cv) = stage[v];
+    }
+    if (t < RT) wt[buf * RT + t] = wstage;
+  };
+
+  int64_t tl = blockIdx.x;
+  if (tl < ntiles) {
+    fetch(tl);
+    deposit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tl < ntiles; tl += gridDim.x) {
+    const int64_t nxt = tl + gridDim.x;
+    if (nxt < ntiles) fetch(nxt);
+    const double* T = tile + buf * RT * LDT;
+#pragma unroll
+    for (int g = 0; g < RT / 4; ++g) {
+      const double* rowp = T + (4 * g + k) * LDT + c;
+      const double wk = wt[buf * RT + 4 * g + k];
+      const double a0 = rowp[16 * ra] * wk, a1 = rowp[16 * rb] * wk;
+#pragma unroll
+      for (int sidx = 0; sidx < NB + 1; ++sidx) {
+        const bool first = sidx < na;
+        const int qb = first ? ra + sidx : rb + (sidx - na);
+        const double b = rowp[16 * qb];
+        acc[sidx] = __builtin_amdgcn_mfma_f64_16x16x4f64(first ? a0 : a1, b, acc[sidx], 0, 0, 0);
+      }
+    }
+    if (nxt < ntiles) deposit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // slab layout: [block id in row-major upper-triangle order][reg][lane]
+#pragma unroll
+  for (int sidx = 0; sidx < NB + 1; ++sidx) {
+    const bool first = sidx < na;
+    const int qa = first ? ra : rb;
+    const int qb = first ? ra + sidx : rb + (sidx - na);
+    const int blkid = qa * NB - qa * (qa - 1) / 2 + (qb - qa);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      partial[(size_t)blockIdx.x * (NB * (NB + 1) / 2 * 256) + (size_t)blkid * 256 + r * 64 + lane] = acc[sidx][r];
+  }
+}
+
+// PP from the slabs of k_xwx_mfma_big (natural column order), fixed summation order.
+template <int NB>
+__global__ __launch_bounds__(1024) void k_reduce_big(const double* __restrict__ partial, int nparts,
+                                                     double* __restrict__ PP)
+{
+  constexpr int P = 16 * NB;
+  constexpr int E = NB * (NB + 1) / 2 * 256;
+  __shared__ double sm[16][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int s = threadIdx.x >> 6;
+  double sum = 0.0;
+  if (e < E)
+    for (int b = s; b < nparts; b += 16) sum += partial[(size_t)b * E + e];
+  sm[s][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (s == 0 && e < E) {
+    const int l = threadIdx.x & 63;
+    double tot = sm[0][l];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tot += sm[q][l];
+    const int blkid = e / 256, reg = (e >> 6) & 3, ln = e & 63;
+    int qa = 0, rem = blkid;
+    while (rem >= NB - qa) {
+      rem -= NB - qa;
+      ++qa;
+    }
+    const int qb = qa + rem;
+    const int i = (ln >> 4) + 4 * reg, j = ln & 15;
+    const int A = 16 * qa + i, B = 16 * qb + j;
+    if (qa != qb || i <= j) {
+      PP[A + (size_t)B * P] = tot;
+      PP[B + (size_t)A * P] = tot;
+    }
+  }
+}
+
 // ======================================================= generic (any P) kernels
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_psi_omega(const double* __restrict__ tX, const double* __restrict__ nvec,
@@ -487,10 +624,10 @@ __device__ bool wg_chol_upper(double* A, int P, int* bad)
     const double d = sqrt(akk);
     __syncthreads();
     if (t == 0) M_(A, k, k) = d;
-    for (int j = k + 1 + t; j < P; j += kBlock) M_(A, k, j) = M_(A, k, j) / d;
+    for (int j = k + 1 + t; j < P; j += (int)blockDim.x) M_(A, k, j) = M_(A, k, j) / d;
     __syncthreads();
     const int m = P - k - 1;
-    for (int e = t; e < m * m; e += kBlock) {
+    for (int e = t; e < m * m; e += (int)blockDim.x) {
       const int i = k + 1 + e % m, j = k + 1 + e / m;
       if (i <= j) M_(A, i, j) -= M_(A, k, i) * M_(A, k, j);
     }
@@ -512,16 +649,16 @@ __device__ bool wg_chol_lower(double* S, int P, int* bad)
     const double d = sqrt(akk);
     __syncthreads();
     if (t == 0) M_(S, k, k) = d;
-    for (int i = k + 1 + t; i < P; i += kBlock) M_(S, i, k) = M_(S, i, k) / d;
+    for (int i = k + 1 + t; i < P; i += (int)blockDim.x) M_(S, i, k) = M_(S, i, k) / d;
     __syncthreads();
     const int m = P - k - 1;
-    for (int e = t; e < m * m; e += kBlock) {
+    for (int e = t; e < m * m; e += (int)blockDim.x) {
       const int i = k + 1 + e % m, j = k + 1 + e / m;
       if (i >= j) M_(S, i, j) -= M_(S, i, k) * M_(S, j, k);
     }
     __syncthreads();
   }
-  for (int e = t; e < P * P; e += kBlock) {
+  for (int e = t; e < P * P; e += (int)blockDim.x) {
     const int i = e % P, j = e / P;
     if (i < j) M_(S, i, j) = 0.0;
   }
@@ -535,10 +672,10 @@ __device__ void wg_solve_Ut(const double* U, double* B, int P, int nrhs, int ldb
   const int t = threadIdx.x;
   for (int i = 0; i < P; ++i) {
     const double d = M_(U, i, i);
-    for (int c = t; c < nrhs; c += kBlock) B[i + (size_t)c * ldb] /= d;
+    for (int c = t; c < nrhs; c += (int)blockDim.x) B[i + (size_t)c * ldb] /= d;
     __syncthreads();
     const int m = P - i - 1;
-    for (int e = t; e < m * nrhs; e += kBlock) {
+    for (int e = t; e < m * nrhs; e += (int)blockDim.x) {
       const int j = i + 1 + e % m, c = e / m;
       B[j + (size_t)c * ldb] -= M_(U, i, j) * B[i + (size_t)c * ldb];
     }
@@ -551,9 +688,9 @@ __device__ void wg_solve_U(const double* U, double* B, int P, int nrhs, int ldb)
   const int t = threadIdx.x;
   for (int i = P - 1; i >= 0; --i) {
     const double d = M_(U, i, i);
-    for (int c = t; c < nrhs; c += kBlock) B[i + (size_t)c * ldb] /= d;
+    for (int c = t; c < nrhs; c += (int)blockDim.x) B[i + (size_t)c * ldb] /= d;
     __syncthreads();
-    for (int e = t; e < i * nrhs; e += kBlock) {
+    for (int e = t; e < i * nrhs; e += (int)blockDim.x) {
       const int j = e % i, c = e / i;
       B[j + (size_t)c * ldb] -= M_(U, j, i) * B[i + (size_t)c * ldb];
     }
@@ -567,7 +704,7 @@ __device__ void wg_solve_L(const double* L, double* b, int P)
   for (int i = 0; i < P; ++i) {
     if (t == 0) b[i] /= M_(L, i, i);
     __syncthreads();
-    for (int j = i + 1 + t; j < P; j += kBlock) b[j] -= M_(L, j, i) * b[i];
+    for (int j = i + 1 + t; j < P; j += (int)blockDim.x) b[j] -= M_(L, j, i) * b[i];
     __syncthreads();
   }
 }
@@ -583,7 +720,7 @@ __device__ __forceinline__ double wave_min(double v)
   return v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
+__global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
   const int P = a.P, t = threadIdx.x;
@@ -593,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
   double* zz = mP + P;
   __shared__ int bad;
   if (t == 0) bad = 0;
-  for (int e = t; e < P * P; e += kBlock) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
+  for (int e = t; e < P * P; e += (int)blockDim.x) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
   __syncthreads();
   if (!wg_chol_upper(A, P, &bad)) {
     __syncthreads();
@@ -602,12 +739,12 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
   }
 
   if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
-    for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+    for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
     if (mode == blk::B_MVN && t < P) {
       // eps_i = r.norm(0,1), i = 0..P-1 in stream order: normal i is exactly block i
       Stream r;
       r.init(a.seed, 0, DOM_BETA, a.epoch);
-      for (int i = t; i < P; i += kBlock) {
+      for (int i = t; i < P; i += (int)blockDim.x) {
         r.blk = (uint32_t)i;
         r.has = false;
         zz[i] = r.norm(0.0, 1.0);
@@ -618,22 +755,22 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
     wg_solve_U(A, mP, P, 1, P);
     if (mode == blk::B_MVN) {
       wg_solve_U(A, zz, P, 1, P);
-      for (int j = t; j < P; j += kBlock) a.beta_out[j] = zz[j] + mP[j];
+      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = zz[j] + mP[j];
     } else {
-      for (int j = t; j < P; j += kBlock) a.beta_out[j] = mP[j];
+      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = mP[j];
     }
     return;
   }
 
   // S = PP^{-1}: two triangular solves on the identity
-  for (int e = t; e < P * P; e += kBlock) S[e] = (e % P == e / P) ? 1.0 : 0.0;
+  for (int e = t; e < P * P; e += (int)blockDim.x) S[e] = (e % P == e / P) ? 1.0 : 0.0;
   __syncthreads();
   wg_solve_Ut(A, S, P, P, P);
   wg_solve_U(A, S, P, P, P);
 
   if (mode == blk::B_FROM_LIK) {
     // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps   (Normal.hpp:98-131)
-    for (int i = t; i < P; i += kBlock) {
+    for (int i = t; i < P; i += (int)blockDim.x) {
       double s = 0.0;
       for (int k2 = 0; k2 < P; ++k2) s += M_(S, i, k2) * a.bP[k2];
       mP[i] = s;
@@ -641,7 +778,7 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
     if (t < P) {
       Stream r;
       r.init(a.seed, 0, DOM_BETA, a.epoch);
-      for (int i = t; i < P; i += kBlock) {
+      for (int i = t; i < P; i += (int)blockDim.x) {
         r.blk = (uint32_t)i;
         r.has = false;
         zz[i] = r.norm(0.0, 1.0);
@@ -653,7 +790,7 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
       if (t == 0) atomicOr(a.status, 8);
       return;
     }
-    for (int i = t; i < P; i += kBlock) {
+    for (int i = t; i < P; i += (int)blockDim.x) {
       double le = 0.0;
       for (int k2 = 0; k2 <= i; ++k2) le += M_(S, i, k2) * zz[k2];
       a.beta_out[i] = le + mP[i];
@@ -662,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
   }
 
   // ---- B_CONSTRAINED: Logit.hpp:322-400 ----
-  for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+  for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
   __syncthreads();
   wg_solve_Ut(A, mP, P, 1, P);
   wg_solve_U(A, mP, P, 1, P);
@@ -679,15 +816,15 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
   int* perm = reinterpret_cast<int*>(sz + P);
   double* Lm = l_in_lds ? sz + P + (P + 1) / 2 + 1 : S;
   if (l_in_lds)
-    for (int e = t; e < P * P; e += kBlock) Lm[e] = S[e];
-  for (int j = t; j < P; j += kBlock) {
+    for (int e = t; e < P * P; e += (int)blockDim.x) Lm[e] = S[e];
+  for (int j = t; j < P; j += (int)blockDim.x) {
     zz[j] = a.beta_prev[j] - mP[j];     // z = beta_prev - mP
     sbeta[j] = a.beta_prev[j];
     perm[j] = j;
   }
   __syncthreads();
   wg_solve_L(S, zz, P);                 // z = L^{-1} z
-  for (int j = t; j < P; j += kBlock) sz[j] = zz[j];
+  for (int j = t; j < P; j += (int)blockDim.x) sz[j] = zz[j];
   __syncthreads();
 
   if (t < 64) {                          // one wavefront runs the serial coordinate sweeps
@@ -727,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void k_beta(blk::BetaArgs a, int mode)
     }
   }
   __syncthreads();
-  for (int j = t; j < P; j += kBlock) a.beta_out[j] = sbeta[j];
+  for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = sbeta[j];
 }
 
 // ============================================= P x P stage, P <= 64: everything on chip
@@ -1361,19 +1498,45 @@ inline int grid_for(int64_t n, int block, int maxb)
 }
 
 template <int NB>
-void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
-               double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
-               int mode, int* status, hipStream_t s)
+void launch_draw_pass(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
+                      const double* off, double* w, int64_t N, uint64_t seed, uint32_t epoch, uint64_t idx0, int mode,
+                      int* status, hipStream_t s)
 {
-  constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
   if (mode == blk::W_DRAW)
     hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_DRAW>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta,
                        off, w, N, seed, epoch, idx0, status);
   else
     hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta, off,
                        w, N, seed, epoch, idx0, status);
+}
+
+template <int NB>
+void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
+               double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
+               int mode, int* status, hipStream_t s)
+{
+  constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
+  launch_draw_pass<NB>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
   hipLaunchKernelGGL((k_xwx_mfma<NB>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, partial);
   hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP);
+}
+
+template <int NB, int NW>
+void launch_nb_big(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
+                   const double* off, double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch,
+                   uint64_t idx0, int mode, int* status, hipStream_t s)
+{
+  constexpr int E = NB * (NB + 1) / 2 * 256;
+  constexpr int P = 16 * NB;
+  constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
+  launch_draw_pass<NB>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_xwx_mfma_big<NB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_xwx_mfma_big<NB, NW>), dim3(plan.nblocks), dim3(NW * 64), lds, s, tX, w, N, partial);
+  hipLaunchKernelGGL((k_reduce_big<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP);
 }
 
 }  // namespace
@@ -1384,7 +1547,19 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
 {
   SweepPlan p;
   p.P = P;
-  if (P % 16 == 0 && P >= 16 && P <= 64) {
+  if (P == 128 || P == 256) {
+    p.fused = 2;                                 // LDS-tiled MFMA kernel, compute-bound
+    p.nb = P / 16;
+    const int64_t ntiles = (N + 15) / 16;
+    int64_t nb = ntiles < 1 ? 1 : ntiles;
+    if (nb > (int64_t)num_cus) nb = num_cus;     // one workgroup (two waves per SIMD) per CU
+    p.nblocks = (int)nb;
+    int64_t nd = ((N + 511) / 512 + 3) / 4;
+    if (nd < 1) nd = 1;
+    if (nd > 4 * (int64_t)num_cus) nd = 4 * (int64_t)num_cus;
+    p.nblocks_draw = (int)nd;
+    p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 256;
+  } else if (P % 16 == 0 && P >= 16 && P <= 64) {
     p.fused = 1;
     p.nb = P / 16;
     const int64_t ntiles = (N + 63) / 64;
@@ -1416,6 +1591,13 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
 {
   const int P = plan.P;
   double* w = w_store ? w_store : w_scratch;
+  if (plan.fused == 2) {
+    if (plan.nb == 8)
+      launch_nb_big<8, 4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+    else
+      launch_nb_big<16, 8>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+    return;
+  }
   if (plan.fused) {
     switch (plan.nb) {
       case 1: launch_nb<1>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
@@ -1500,7 +1682,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), lds, s, a, mode);
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), lds, s, a, mode);
 }
 
 void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s)

@@ -32,7 +32,7 @@ def shard_of(X, y, n, gpu, seed, idx0=0):
 
 
 @pytest.mark.parametrize("N,P", [(1000, 64), (64, 64), (65, 64), (4097, 32), (777, 16), (300, 48), (1500, 48),
-                                 (500, 10), (200, 1), (333, 70), (2000, 70), (150, 130), (2600, 130), (20000, 130)])
+                                 (500, 10), (200, 1), (333, 70), (2000, 70), (150, 130), (2600, 130), (20000, 130), (3000, 128), (1001, 256), (17, 128)])
 def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     """fused MFMA path (P in 16,32,48,64) and the generic path (other P), ragged N included."""
     from bayeslogit_amd import device as D
