@@ -19,6 +19,7 @@ struct SweepPlan {
   int fused = 0;          // 1: MFMA path, registers (P in {16,32,48,64}); 2: MFMA path, LDS tiles (P in {128,256}); 0: generic
   int nblocks = 0;        // workgroups of the X'WX kernel (= number of partial slabs)
   int nblocks_draw = 0;   // workgroups of the psi/omega kernel
+  int chunk_rows = 0;     // rows a wave of the psi/omega kernel takes at a time (multiple of 64, <= 512)
   int nb = 0;             // fused: P/16
   int ntile = 0;          // generic: number of 64x64 output tiles (upper triangle)
   size_t partial_doubles = 0;   // workspace size

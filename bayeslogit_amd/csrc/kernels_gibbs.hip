@@ -15,7 +15,7 @@
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
 #include "bl_gibbs_kernels.hpp"
 #include "bl_pg_devroye.hpp"
-#include "bl_pg1_sm.hpp"
+#include "bl_pg1_queue.hpp"
 #include "../../include/bayeslogit_hip.h"
 
 namespace {
@@ -72,29 +72,41 @@ __device__ __forceinline__ void load_group(double (&xg)[NB], const double* __res
   } else {
 #pragma unroll
     for (int h = 0; h < NB / 2; ++h) {
-      const v2d v = *reinterpret_cast<const v2d*>(p + 32 * h + 2 * c);
+      const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + 32 * h + 2 * c));
       xg[2 * h] = ok ? v.x : 0.0;
       xg[2 * h + 1] = ok ? v.y : 0.0;
     }
   }
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dppmov_f64(double v)      // every lane has a valid source: no `old` copy
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 // ---- pass 1: psi = X beta (- off), omega ~ PG(n, psi) -> w[]          (Logit.hpp:431,283-289)
-// A wave takes super-tiles of kSuper rows.  Phase 1 streams the rows once (coalesced 16-byte
-// loads), forms psi by a 16-lane butterfly and leaves the proposal mass of every row in LDS;
-// phase 2 is the work-queue state machine of kernels_pg.hip's k_rpg_devroye.
+// A wave takes chunks of `chunk` <= kSuper rows (make_plan sizes them so that every resident wave
+// gets the same number of chunks).  Phase 1 streams the rows once (coalesced 16-byte loads),
+// forms psi by a 16-lane butterfly, parks psi in w[] (re-read from L2 when a lane starts the
+// row), leaves the proposal mass in LDS and compacts the rows by sampler class into two index
+// lists; phase 2 is the work queue of bl_pg1_queue.hpp, once per class -- the same structure as
+// kernels_pg.hip's k_rpg_devroye with X beta in place of a z vector.
 constexpr int kSuper = 512;
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(kBlock) void k_psi_omega_nb(const double* __restrict__ tX,
-                                                         const double* __restrict__ nvec,
-                                                         const double* __restrict__ beta,
-                                                         const double* __restrict__ off,
-                                                         double* __restrict__ w, int64_t N, uint64_t seed,
-                                                         uint32_t epoch, uint64_t idx0, int* __restrict__ status)
+__global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __restrict__ tX,
+                                                            const double* __restrict__ nvec,
+                                                            const double* __restrict__ beta,
+                                                            const double* __restrict__ off,
+                                                            double* __restrict__ w, int64_t N, int chunk,
+                                                            uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                            int* __restrict__ status)
 {
-  __shared__ double sZ[kBlock / 64][kSuper];
   __shared__ double sM[kBlock / 64][kSuper];
+  __shared__ double sZ[kBlock / 64][kSuper];
+  __shared__ unsigned short sIdx[kBlock / 64][kSuper];   // class 1 from the front, class 2 from the back
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, c = lane & 15;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -104,11 +116,15 @@ __global__ __launch_bounds__(kBlock) void k_psi_omega_nb(const double* __restric
 #pragma unroll
   for (int q = 0; q < NB; ++q) bq[q] = beta[colmap<NB>(q, c)];
 
-  const int64_t nsuper = (N + kSuper - 1) / kSuper;
-  for (int64_t sp = (int64_t)blockIdx.x * (kBlock / 64) + wave; sp < nsuper; sp += (int64_t)gridDim.x * (kBlock / 64)) {
-    const int64_t base = sp * kSuper;
-    const int cnt = (int)((N - base) < kSuper ? (N - base) : kSuper);
-    // phase 1: psi for the rows of the super-tile, 64 rows (16 groups) at a time
+  // this wave's contiguous row range, cut into chunks
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t per_wave = ((N + nwaves - 1) / nwaves + 63) / 64 * 64;
+  const int64_t r0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * per_wave;
+  const int64_t r1 = (r0 + per_wave) < N ? (r0 + per_wave) : N;
+  for (int64_t base = r0; base < r1;) {
+    const int cnt = (int)((r1 - base) < chunk ? (r1 - base) : chunk);
+    int nA = 0, nB = 0;   // wave-uniform list lengths
+    // phase 1: psi for the rows of the chunk, 64 rows (16 groups) at a time
     for (int t0 = 0; t0 < cnt; t0 += 64) {
       double psi = 0.0;
 #pragma unroll 4
@@ -126,68 +142,39 @@ __global__ __launch_bounds__(kBlock) void k_psi_omega_nb(const double* __restric
         psi = (c == g) ? part : psi;
       }
       const int slot = t0 + 4 * c + k;          // the row whose psi this lane kept
+      bool small = false, large = false;
       if (slot < cnt) {
         if (off) psi -= off[base + slot];
         if (MODE == blk::W_DRAW) {
           const Pg1Par p = pg1_par(psi);
-          sZ[wave][slot] = p.Z;
+          sZ[wave][slot] = psi;
           sM[wave][slot] = p.mass;
+          small = kSmTRecip > p.Z;              // PolyaGamma.cpp:87
+          large = !small;
         } else {
           w[base + slot] = weight_of<MODE>(psi, nvec[base + slot], seed, 0, epoch, st_flags);
         }
       }
+      if (MODE == blk::W_DRAW) {
+        const uint64_t ma = __ballot(small), mb = __ballot(large);
+        if (small) sIdx[wave][nA + __popcll(ma & lt_mask)] = (unsigned short)slot;
+        if (large) sIdx[wave][kSuper - 1 - (nB + __popcll(mb & lt_mask))] = (unsigned short)slot;
+        nA += __popcll(ma);
+        nB += __popcll(mb);
+      }
     }
-    if (MODE != blk::W_DRAW) continue;
+    if (MODE != blk::W_DRAW) { base += cnt; continue; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    // phase 2: work queue over the super-tile
-    int next = 0, q = -1, nrem = 0;
-    uint32_t c0 = 0, c1 = 0, blk = 0;
-    double sum = 0.0;
-    Pg1Par par{0.0, 1.0, 0.5};
-    Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
-    for (;;) {
-      const bool idle = q < 0;
-      const uint64_t im = __ballot(idle);
-      if (im != 0 && next < cnt) {
-        const int cand = next + __popcll(im & lt_mask);
-        if (idle && cand < cnt) {
-          int n = (int)nvec[base + cand];                       // (int) n(i), Logit.hpp:287
-          if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }      // PolyaGamma.cpp:128-135 (NTHROW)
-          q = cand;
-          nrem = n;
-          par.Z = sZ[wave][cand];
-          par.mass = sM[wave][cand];
-          par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
-          const uint64_t idx = idx0 + (uint64_t)(base + cand);
-          c0 = (uint32_t)idx;
-          c1 = ctr1_of(idx, DOM_DRAW);
-          blk = 0;
-          sum = 0.0;
-          sm.st = SM_BRANCH;
-        }
-        next += __popcll(im);
-      }
-      if (__ballot(q >= 0) == 0) {
-        if (next >= cnt) break;
-        continue;
-      }
-      if (q >= 0) {
-        const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
-        blk += 1;
-        if (pg1_advance(sm, par, u52(o.x, o.y), st_flags)) {
-          sum += 0.25 * sm.X;
-          if (--nrem == 0) { w[base + q] = sum; q = -1; }
-        }
-        if (q >= 0 && pg1_advance(sm, par, u52(o.z, o.w), st_flags)) {
-          sum += 0.25 * sm.X;
-          if (--nrem == 0) { w[base + q] = sum; q = -1; }
-        }
-        if (blk > 4000000u) { st_flags |= ST_ITER_CAP; w[base + q] = sum; q = -1; }
-      }
-    }
+    // phase 2: work queue per class; psi is read back from w[], omega overwrites it
+    if (nA > 0)
+      devroye_queue<1, 2, double>(&sIdx[wave][0], nA, sZ[wave], sM[wave], w, nvec, 1, base, idx0, epoch, k0, k1,
+                                     lt_mask, st_flags);
+    if (nB > 0)
+      devroye_queue<2, 2, double>(&sIdx[wave][kSuper - nB], nB, sZ[wave], sM[wave], w, nvec, 1, base, idx0, epoch,
+                                     k0, k1, lt_mask, st_flags);
     __builtin_amdgcn_wave_barrier();
+    base += cnt;
   }
   if (st_flags) atomicOr(status, st_flags);
 }
@@ -918,13 +905,6 @@ __device__ __forceinline__ double dpp_f64_rm(double v)
 // of 16 lanes (4 DPP levels), then row_bcast15 / row_bcast31 fold the four rows into row 3.
 // (A float-key fast path -- one VOP2-DPP op per level, winner located by ballot -- was tried and
 // measured slower: its VALU->SGPR->branch crossings cost more than the 64-bit moves they save.)
-template <int CTRL>
-__device__ __forceinline__ double dppmov_f64(double v)      // every lane has a valid source: no `old` copy
-{
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
 {
   mx = vmax64(mx, dppmov_f64<0xB1>(mx));  mn = vmin64(mn, dppmov_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
@@ -1504,10 +1484,10 @@ void launch_draw_pass(const blk::SweepPlan& plan, const double* tX, const double
 {
   if (mode == blk::W_DRAW)
     hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_DRAW>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta,
-                       off, w, N, seed, epoch, idx0, status);
+                       off, w, N, plan.chunk_rows, seed, epoch, idx0, status);
   else
     hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta, off,
-                       w, N, seed, epoch, idx0, status);
+                       w, N, plan.chunk_rows, seed, epoch, idx0, status);
 }
 
 template <int NB>
@@ -1543,6 +1523,25 @@ void launch_nb_big(const blk::SweepPlan& plan, const double* tX, const double* n
 
 namespace blk {
 
+// psi/omega pass: two 4-wave workgroups per CU are resident (launch bounds of k_psi_omega_nb);
+// every wave takes r chunks of chunk_rows rows, r the smallest count that keeps chunk_rows <= kSuper,
+// so the grid has no partial last round.
+static void plan_draw_pass(SweepPlan& p, int64_t N, int num_cus)
+{
+  const int64_t waves = 2 * 4 * (int64_t)num_cus;
+  const int64_t r = (N + waves * kSuper - 1) / (waves * kSuper);
+  int64_t chunk = (N + waves * r - 1) / (waves * (r < 1 ? 1 : r));
+  chunk = (chunk + 63) / 64 * 64;
+  if (chunk < 64) chunk = 64;
+  if (chunk > kSuper) chunk = kSuper;
+  const int64_t nchunks = (N + chunk - 1) / chunk;
+  int64_t nd = (nchunks + 3) / 4;
+  if (nd < 1) nd = 1;
+  if (nd > 2 * (int64_t)num_cus) nd = 2 * (int64_t)num_cus;
+  p.chunk_rows = (int)chunk;
+  p.nblocks_draw = (int)nd;
+}
+
 SweepPlan make_plan(int64_t N, int P, int num_cus)
 {
   SweepPlan p;
@@ -1554,10 +1553,7 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     int64_t nb = ntiles < 1 ? 1 : ntiles;
     if (nb > (int64_t)num_cus) nb = num_cus;     // one workgroup (two waves per SIMD) per CU
     p.nblocks = (int)nb;
-    int64_t nd = ((N + 511) / 512 + 3) / 4;
-    if (nd < 1) nd = 1;
-    if (nd > 4 * (int64_t)num_cus) nd = 4 * (int64_t)num_cus;
-    p.nblocks_draw = (int)nd;
+    plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 256;
   } else if (P % 16 == 0 && P >= 16 && P <= 64) {
     p.fused = 1;
@@ -1567,10 +1563,7 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     if (nb < 1) nb = 1;
     if (nb > 2 * (int64_t)num_cus) nb = 2 * (int64_t)num_cus;   // pass 2: two 4-wave workgroups per CU
     p.nblocks = (int)nb;
-    int64_t nd = ((N + 511) / 512 + 3) / 4;
-    if (nd < 1) nd = 1;
-    if (nd > 4 * (int64_t)num_cus) nd = 4 * (int64_t)num_cus;   // pass 1: grid-stride over 512-row super-tiles
-    p.nblocks_draw = (int)nd;
+    plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 4 * 64;
   } else {
     p.fused = 0;

@@ -3,7 +3,7 @@
 // Code/C/LogitWrapper.cpp:39-167.  gfx950 only.
 #include "bl_host.hpp"
 #include "bl_pg_hybrid.hpp"
-#include "bl_pg1_sm.hpp"
+#include "bl_pg1_queue.hpp"
 
 namespace {
 
@@ -28,65 +28,6 @@ constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride
 // The stream belongs to the observation, so which lane draws it, and when, does not change the
 // result.
 constexpr int kChunk = 1024;   // 16 observations per lane: the queue's drain tail is ~8% of a chunk
-
-template <int ZC>
-__device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__ list, int cnt,
-                                              const double* __restrict__ z, const double* __restrict__ sM,
-                                              double* __restrict__ x, const int* __restrict__ nvec, int nscalar,
-                                              int64_t base, uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
-                                              uint64_t lt_mask, int& st_flags)
-{
-  int next = 0;      // wave-uniform: first unstarted entry of the list
-  int q = -1;        // this lane's observation (slot in the chunk), -1 = idle
-  int nrem = 0;
-  uint32_t c0 = 0, c1 = 0, blk = 0;
-  double sum = 0.0;
-  Pg1Par par{0.0, 1.0, 0.5};
-  Pg1Lane sm{SM_BRANCH, 0.0, 0.0};
-  for (;;) {
-    const bool idle = q < 0;
-    const uint64_t im = __ballot(idle);
-    if (im != 0 && next < cnt) {
-      const int cand = next + __popcll(im & lt_mask);
-      if (idle && cand < cnt) {
-        const int slot = list[cand];
-        int n = nvec ? nvec[base + slot] : nscalar;
-        if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }       // PolyaGamma.cpp:128-135 (NTHROW)
-        q = slot;
-        nrem = n;
-        par.Z = fabs(z[base + slot]) * 0.5;          // re-read (L2): only the mass is staged in LDS
-        par.mass = sM[slot];
-        par.fz = kSmPiSq8 + 0.5 * par.Z * par.Z;
-        const uint64_t idx = idx0 + (uint64_t)(base + slot);
-        c0 = (uint32_t)idx;
-        c1 = ctr1_of(idx, DOM_DRAW);
-        blk = 0;
-        sum = 0.0;
-        sm.st = SM_BRANCH;
-      }
-      next += __popcll(im);
-    }
-    if (__ballot(q >= 0) == 0) {
-      if (next >= cnt) break;
-      continue;
-    }
-    if (q >= 0) {
-      const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
-      blk += 1;
-      double u = u52(o.x, o.y);
-      const double u_second = u52(o.z, o.w);
-#pragma unroll 1
-      for (int half = 0; half < 2 && q >= 0; ++half) {
-        if (pg1_advance<true, false, ZC>(sm, par, u, st_flags)) {
-          sum += 0.25 * sm.X;
-          if (--nrem == 0) { x[base + q] = sum; q = -1; }
-        }
-        u = u_second;
-      }
-      if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
-    }
-  }
-}
 
 __global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
                                                            int nscalar, const double* __restrict__ z, int64_t num,
@@ -127,9 +68,9 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (nA > 0)
-      devroye_queue<1>(&sIdx[wave][0], nA, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+      devroye_queue<1, 0, int>(&sIdx[wave][0], nA, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask, st_flags);
     if (nB > 0)
-      devroye_queue<2>(&sIdx[wave][kChunk - nB], nB, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask,
+      devroye_queue<2, 0, int>(&sIdx[wave][kChunk - nB], nB, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask,
                        st_flags);
     __builtin_amdgcn_wave_barrier();
   }

@@ -243,6 +243,66 @@ def test_full_size_C4_properties(gpu):
     g.close()
 
 
+def test_full_size_C5_shard_properties(gpu):
+    """One GPU's shard of BASELINE C5 (N = 1e8, P = 256 over 8 GPUs: 12.5e6 rows, 25.6 GB, 3.2e9 > 2^31
+    elements, so every index on the path must be 64-bit).  Size-independent checks on one sweep at that
+    size: PP exactly symmetric, trace(PP) and PP 1 against torch reductions over the same omega, the LAST
+    rows of the shard really contribute (PP changes when they are zeroed), E[omega] against the closed
+    form, and the same rows at a shifted idx0 reproduce the draws of the unsplit problem."""
+    from bayeslogit_amd import device as D
+    N, P = 12_500_000, 256
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GB of free HBM")
+    X = torch.empty((N, P), dtype=torch.float64, device=gpu)
+    D.fill_norm(X, 0.0, 1.0 / 16.0, 20240005)
+    X[:, -1] = 1.0
+    beta = torch.linspace(0.0, 1.0, P, dtype=torch.float64, device=gpu)
+    n = torch.ones(N, dtype=torch.float64, device=gpu)
+    g = D.GibbsShard(X, None, n, seed=20240006)
+    g.set_beta(beta.cpu().numpy())
+    w = torch.empty(N, dtype=torch.float64, device=gpu)
+    g.sweep_local(0, w)
+    D.sync_status()
+    PP = g.pp().clone().reshape(P, P)
+    assert torch.equal(PP, PP.T)
+    tr = 0.0
+    ref = torch.zeros(P, dtype=torch.float64, device=gpu)
+    psi = torch.empty(N, dtype=torch.float64, device=gpu)
+    step = 1_250_000
+    for a in range(0, N, step):
+        Xc = X[a:a + step]
+        wc = w[a:a + step]
+        tr += (wc * (Xc * Xc).sum(1)).sum().item()
+        ref += Xc.T @ (wc * Xc.sum(1))
+        psi[a:a + step] = Xc @ beta
+    assert abs(PP.diagonal().sum().item() / tr - 1) < 1e-11
+    assert torch.allclose(PP.sum(1), ref, rtol=1e-10, atol=1e-8)
+    za = psi.abs().clamp_min(1e-12)
+    assert abs(w.mean().item() - (torch.tanh(za / 2) / (2 * za)).mean().item()) < 6 * np.sqrt(0.05 / N)
+    # the tail of the shard (element offsets beyond 2^31) is read: dropping it changes PP by exactly its term
+    tail = 1000
+    Xt = X[N - tail:].clone()
+    X[N - tail:] = 0.0
+    g.sweep_local(0, None)
+    D.sync_status()
+    PP2 = g.pp().clone().reshape(P, P)
+    X[N - tail:] = Xt
+    d = (PP - PP2)
+    dref = Xt.T @ (w[N - tail:, None] * Xt)
+    assert torch.allclose(d, dref, rtol=1e-7, atol=1e-9)
+    g.close()
+    # shard invariance at this size: the last 1e6 rows as their own shard with idx0 = N - 1e6
+    m = 1_000_000
+    g2 = D.GibbsShard(X[N - m:], None, n[N - m:], seed=20240006, idx0=N - m)
+    g2.set_beta(beta.cpu().numpy())
+    w2 = torch.empty(m, dtype=torch.float64, device=gpu)
+    g2.sweep_local(0, w2)
+    D.sync_status()
+    assert torch.equal(w2, w[N - m:])
+    g2.close()
+
+
 def test_dist_driver_with_hip_shard(gpu, oracle):
     """bayeslogit_amd.dist.DistGibbs driving the real HIP shard (world size 1: the collectives are
     no-ops, the sequencing and the library-owned P*P / P buffers exposed as torch tensors are real)."""
