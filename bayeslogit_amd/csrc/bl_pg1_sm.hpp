@@ -1,25 +1,43 @@
-// bl_pg1_sm.hpp -- PG(1, z) by Devroye's method as a lane-uniform state machine.
+// bl_pg1_sm.hpp -- PG(1, z) by Devroye's method, one Philox block per proposal attempt.
 //
-// Same sampler as Code/C/PolyaGamma.cpp:151-202 (and rtigauss :82-115, mass_texpon
-// :65-80, a() :41-55): same proposals, same accept/reject events, and the uniforms of
-// the observation's stream are consumed in the same order with the same meaning, so a
-// draw equals the straight-line restatement's to rounding.  What changes is the shape
-// of the computation, for 64-wide wavefronts:
-//   * one TRANSITION consumes one uniform and moves a lane from state to state; every
-//     lane of a wave runs the same short transition body (one log, one divide, one exp;
-//     bl_fastmath.hpp's 38- and 24-instruction forms)
-//     whatever state it is in, instead of each lane spinning in its own nested
-//     rejection loops while the others wait;
-//   * the proposal mass (mass_texpon) is evaluated without log/exp/erfc: both exponents
-//     of PolyaGamma.cpp:73-75 collapse to the constant  t pi^2/8 - 1/(2t)  once
-//     log Phi is written with the scaled erfc, leaving two Chebyshev sums;
-//   * the first alternating-series test  U a_0 <= a_0 - a_1  is done on the ratio
-//     a_1/a_0 (one exp); only the ~8e-4 of proposals that fail it walk the series,
-//     in the reference's literal arithmetic.
+// Same sampler as Code/C/PolyaGamma.cpp:151-202 (with rtigauss :82-115, mass_texpon :65-80,
+// a() :41-55): the same mixture proposal (exponential piece right of t = 0.64 with probability
+// mass_texpon(Z), inverse-Gaussian piece left of it), the same acceptance events with the same
+// probabilities, the same alternating-series test.  What changes is how the observation's
+// uniforms are spent, so that a 64-wide wavefront runs ONE short, state-free body per attempt
+// instead of each lane spinning in its own nested rejection loops:
+//
+//   * one ATTEMPT consumes one Philox4x32-10 block = two uniforms (u1, u2).  u1 chooses the piece
+//     and -- recycled: conditional on {u1 < p}, u1/p is again uniform and independent of the
+//     event -- also drives the proposal variate; u2 decides every accept/reject event of the
+//     attempt through nested thresholds (conditional on {u2 <= A}, u2/A is uniform):
+//        right piece   E = -log(u1/mass),  X = t + E/fz                                 :171
+//                      accept  u2 <= 1 - a_1(X)/a_0(X)                                   :175-192
+//        left, mu > t  E1 = -log(w),  X = t/(1 + t E1)^2                                 :94-99
+//                      pair kept (E1^2 <= 2 E2/t, E2 ~ Exp(1): probability exp(-t E1^2/2)) :95
+//                      AND `unif <= alpha = exp(-Z^2 X/2)`                               :89,100
+//                        <=>  u2 <= A = exp(-t E1^2/2 - Z^2 X/2);   else a new pair (both
+//                             rejections restart at the same point of the reference's loops)
+//                      accept  u2/A <= 1 - a_1(X)/a_0(X)
+//        left, mu <= t Y = qnorm(w)^2, X0 as :107-109, reciprocal flip on u2 vs mu/(mu+X0) :110-111,
+//                      retry while X > t :105, accept on the recycled remainder of u2
+//     with w = (u1 - mass)/(1 - mass) on the attempt that chose the left piece and w = u1 on the
+//     retries inside it.  E2 and the initial `unif() > 0` of :88-89 never reach the result and
+//     are not drawn.
+//   * the proposal mass (mass_texpon) is evaluated without log/exp/erfc: both exponents of
+//     PolyaGamma.cpp:73-75 collapse to the constant  t pi^2/8 - 1/(2t)  once log Phi is written
+//     with the scaled erfc, leaving two Chebyshev sums;
+//   * the first alternating-series test  U a_0 <= a_0 - a_1  is done on the ratio a_1/a_0
+//     (3 exp(-pi^2 X) right of t, 3 exp(-4/X) left of it; both < 0.006, so the exponential is
+//     only evaluated when some lane of the wave has u2 within 0.006 of its threshold); only the
+//     ~8e-4 of proposals that fail it walk the series, in the reference's literal arithmetic.
+// The test suite's CPU checker holds the same attempt in plain C next to a call-for-call
+// restatement of the reference loops, and pins the two to the same distribution.
 #pragma once
 #include "bl_erfcx.hpp"
 #include "bl_fastmath.hpp"
 #include "bl_philox.hpp"
+#include "bl_qnorm.hpp"
 
 namespace bl {
 
@@ -30,30 +48,21 @@ constexpr double kSmPiSq8 = kSmPi * kSmPi / 8.0;
 constexpr double kSmPiSq = kSmPi * kSmPi;
 constexpr double kSmInvSqrt2T = 0.88388347648318440550105545263106;   // 1/sqrt(2 * 0.64)
 constexpr double kSmLogHalfPi = 0.45158270528945486472619522989488;
-
-enum Pg1St : int {
-  SM_BRANCH = 0,   // u decides exponential (right) vs inverse-Gaussian (left) piece   :170
-  SM_RIGHT_E,      // u -> X = t + Exp(1)/fz                                           :171
-  SM_ACCEPT,       // u -> Y = u a_0(X); alternating series                            :175-199
-  SM_L_TEST,       // u vs alpha (alpha = 0 on entry): `while (r.unif() > alpha)`      :89
-  SM_L_E1,         // u -> E1                                                          :94
-  SM_L_E2,         // u -> E2; pair accepted if E1^2 <= 2 E2 / t, then X, alpha        :94-100
-  SM_G_N1,         // mu <= t branch: first uniform of the normal                      :106
-  SM_G_N2,         // second uniform of the normal -> candidate X                      :106-109
-  SM_G_U,          // u vs mu/(mu+X): reciprocal flip; loop while X > t                :110-111
-  SM_DONE
-};
+constexpr double kSmRatioMax = 0.006;   // > 3 exp(-pi^2 t) = 0.00542 and > 3 exp(-4/t) = 0.00579
+constexpr double kSmWMin = 0x1.0p-53, kSmWMax = 1.0 - 0x1.0p-53;   // recycled uniforms stay inside (0,1)
 
 struct Pg1Par {      // per observation, from z
   double Z;          // |z|/2
   double fz;         // pi^2/8 + Z^2/2
   double mass;       // mass_texpon(Z)
+  double im;         // 1/mass
+  double il;         // 1/(1 - mass)
 };
 
 struct Pg1Lane {     // per lane
-  int st;
-  double X;          // current proposal
-  double aux;        // E1 / alpha / log(u1), depending on state
+  bool fresh;        // true: the attempt starts a new proposal (u1 picks the piece);
+                     // false: it is a retry inside the left piece
+  double X;          // the accepted proposal when an attempt completes a draw
 };
 
 // mass_texpon(Z), PolyaGamma.cpp:65-80, rewritten (see header comment):
@@ -74,12 +83,21 @@ BL_HD double pg1_mass(double Z, double fz)
   return 1.0 / (1.0 + qdivp);
 }
 
+// the reciprocals the recycling needs, from (Z, mass)
+BL_HD void pg1_par_finish(Pg1Par& p)
+{
+  p.fz = kSmPiSq8 + 0.5 * p.Z * p.Z;                  // :157
+  p.im = bl_div(1.0, p.mass);
+  p.il = bl_div(1.0, 1.0 - p.mass);
+}
+
 BL_HD Pg1Par pg1_par(double z)
 {
   Pg1Par p;
   p.Z = fabs(z) * 0.5;                                // :154
-  p.fz = kSmPiSq8 + 0.5 * p.Z * p.Z;                  // :157
+  p.fz = kSmPiSq8 + 0.5 * p.Z * p.Z;
   p.mass = pg1_mass(p.Z, p.fz);
+  pg1_par_finish(p);
   return p;
 }
 
@@ -113,145 +131,93 @@ BL_HD_COLD bool pg1_series(double X, double u, int& status)
   return true;
 }
 
-// The mu <= t inverse-Gaussian branch (|z| >= 3.125), PolyaGamma.cpp:103-113: out of line so
-// that its square roots, cospi and divides do not inflate the registers of the common path.
-BL_HD_COLD void pg1_advance_g(Pg1Lane& s, const Pg1Par& p, double u, double lu)
+// true if any lane of the wavefront has `need` set (host build: the one caller)
+BL_HD bool pg1_any(bool need)
 {
-  const double mu = 1.0 / p.Z;
-  if (s.st == SM_G_N1) {
-    s.aux = lu;
-    s.st = SM_G_N2;
-  } else if (s.st == SM_G_N2) {                                                  // :104-109
-    double Y = sqrt(-2.0 * s.aux) * BL_COSPI(2.0 * u);                           // r.norm(1.0)
-    Y *= Y;
-    const double half_mu = 0.5 * mu;
-    const double mu_Y = mu * Y;
-    s.X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-    s.st = SM_G_U;
-  } else {                                                                       // :110-111, :105
-    if (u > mu / (mu + s.X)) s.X = mu * mu / s.X;
-    s.st = (s.X > kSmT) ? SM_G_N1 : SM_ACCEPT;
-  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(need) != 0ull;
+#else
+  return need;
+#endif
 }
 
-// same, inlined
-BL_HD void pg1_advance_g_inl(Pg1Lane& s, const Pg1Par& p, double u, double lu)
+// Outcome of an attempt once X, the threshold A of u2 and the exponent of a_1/a_0 are known.
+// Sets s.fresh for the next attempt; returns true when the draw is complete (value 0.25 * s.X).
+template <bool FAST>
+BL_HD bool pg1_decide(Pg1Lane& s, double X, double A, double rarg, double u2, int& status)
 {
-  const double mu = 1.0 / p.Z;
-  if (s.st == SM_G_N1) {
-    s.aux = lu;
-    s.st = SM_G_N2;
-  } else if (s.st == SM_G_N2) {                                                  // :104-109
-    double Y = sqrt(-2.0 * s.aux) * BL_COSPI(2.0 * u);                           // r.norm(1.0)
-    Y *= Y;
-    const double half_mu = 0.5 * mu;
-    const double mu_Y = mu * Y;
-    s.X = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-    s.st = SM_G_U;
-  } else {                                                                       // :110-111, :105
-    if (u > mu / (mu + s.X)) s.X = mu * mu / s.X;
-    s.st = (s.X > kSmT) ? SM_G_N1 : SM_ACCEPT;
+  if (u2 > A) {                      // left piece only (A = 1 on the right): a new pair / candidate
+    s.fresh = false;
+    return false;
   }
+  bool ok = u2 <= A * (1.0 - kSmRatioMax);
+  if (pg1_any(!ok)) {
+    const double r3 = 3.0 * (FAST ? bl_exp(rarg) : exp(rarg));
+    if (!ok) {
+      ok = u2 <= A * (1.0 - r3);
+      if (!ok) ok = pg1_series(X, u2 / A, status);                               // rare
+    }
+  }
+  s.fresh = true;                    // accepted: next draw; rejected: new proposal, :167
+  s.X = X;
+  return ok;
 }
 
-// One transition: consume uniform u.  Returns true when a draw has completed; the draw
-// is then 0.25 * lane.X and the lane is back in SM_BRANCH for the next one.
-// FAST: bl_fastmath log/exp (default) or libm's; COLDG: large-|z| branch out of line or inline
-// (inline measured faster on gfx950 at 3 waves/SIMD: 8.6 vs 9.7 ms per 1e8 draws, z ~ U(0,4)).
+// One attempt: consume the block (u1, u2).  Returns true when a draw has completed; the draw is
+// then 0.25 * lane.X and the lane is ready for the next one.
+// FAST: bl_fastmath log/exp (default) or libm's.
 // ZC: what the caller guarantees about the lane's observation -- 0 nothing, 1 |z|/2 < 1/t (the
-// mu > t inverse-Gaussian branch: states L_*), 2 |z|/2 >= 1/t (states G_*).  A wave whose lanes
-// all hold observations of one class compiles and executes only that class's states.
-template <bool FAST = true, bool COLDG = false, int ZC = 0>
-BL_HD bool pg1_advance(Pg1Lane& s, const Pg1Par& p, double u, int& status)
+// mu > t inverse-Gaussian branch), 2 |z|/2 >= 1/t.  A wave whose lanes all hold observations of
+// one class compiles and executes only that class's left piece.
+template <bool FAST = true, int ZC = 0>
+BL_HD bool pg1_attempt(Pg1Lane& s, const Pg1Par& p, double u1, double u2, int& status)
 {
-  const int st = s.st;
-  // ---- common body: one log, one divide, one exp, whatever the state ----
-  const double lu = FAST ? bl_log(u) : log(u);
-  // the one division: E/fz (RIGHT_E, :171), t/(1+t E1)^2 (L_E2, :98-99), -4/X (ACCEPT, left piece)
-  double num = -lu, den = p.fz;
-  if (ZC != 2 && st == SM_L_E2) {
-    const double d = 1.0 + s.aux * kSmT;
-    num = kSmT;
-    den = d * d;
-  }
-  if (st == SM_ACCEPT) {
-    num = -4.0;
-    den = s.X;
-  }
-  const double q = FAST ? bl_div(num, den) : num / den;
-  double Xc = s.X;
-  if (st == SM_RIGHT_E) Xc = kSmT + q;
-  if (ZC != 2 && st == SM_L_E2) Xc = q;
-  // the one exponential: alpha = exp(-Z^2 X/2) (L_E2, :100) or a_1/a_0 = 3 exp(.) (ACCEPT)
-  double earg = -0.5 * p.Z * p.Z * Xc;
-  if (st == SM_ACCEPT) earg = Xc > kSmT ? -kSmPiSq * Xc : q;
-  const double ex = FAST ? bl_exp(earg) : exp(earg);
+  const bool right = s.fresh && u1 < p.mass;                                     // :170
+  double w = s.fresh ? (right ? u1 * p.im : (u1 - p.mass) * p.il) : u1;
+  w = w < kSmWMin ? kSmWMin : w;
+  w = w > kSmWMax ? kSmWMax : w;
+  const bool small = ZC == 1 || (ZC == 0 && kSmTRecip > p.Z);                    // :87, mu > t
 
-  bool finished = false;
-  switch (st) {
-    case SM_BRANCH:
-      if (u < p.mass) {
-        s.st = SM_RIGHT_E;
-      } else if (ZC == 1 || (ZC == 0 && kSmTRecip > p.Z)) {                      // :87, mu > t
-        s.st = SM_L_TEST;
-        s.aux = 0.0;                                                             // alpha = 0, :88
-      } else {
-        s.st = SM_G_N1;
-      }
-      break;
-    case SM_RIGHT_E:
-      s.X = Xc;
-      s.st = SM_ACCEPT;
-      break;
-    case SM_L_TEST:                                                              // :89
-      if (ZC != 2) s.st = (u > s.aux) ? SM_L_E1 : SM_ACCEPT;
-      break;
-    case SM_L_E1:
-      if (ZC != 2) {
-        s.aux = -lu;                                                             // E1
-        s.st = SM_L_E2;
-      }
-      break;
-    case SM_L_E2:
-      if (ZC != 2) {
-        const double E1 = s.aux, E2 = -lu;
-        if (E1 * E1 > 2.0 * E2 / kSmT) {                                         // :95
-          s.st = SM_L_E1;
-        } else {
-          s.X = Xc;
-          s.aux = ex;                                                            // alpha
-          s.st = SM_L_TEST;
-        }
-      }
-      break;
-    case SM_ACCEPT: {
-      // U a_0 <= a_0 - a_1  <=>  U <= 1 - a_1/a_0 ;  X <= 0 cannot occur (X > 0 always)
-      bool ok = u <= 1.0 - 3.0 * ex;
-      if (!ok) ok = pg1_series(s.X, u, status);                                  // rare
-      if (ok) {
-        finished = true;
-        s.st = SM_BRANCH;
-      } else {
-        s.st = SM_BRANCH;                                                        // new proposal, :167
-      }
-    } break;
-    case SM_G_N1:
-    case SM_G_N2:
-    case SM_G_U:
-      if (ZC != 1) {
-        if (COLDG) pg1_advance_g(s, p, u, lu);
-        else pg1_advance_g_inl(s, p, u, lu);
-      }
-      break;
-    default: break;
+  if (ZC != 2 && (right || small)) {
+    // exponential piece and the mu > t left piece share one body: one log, one divide, one exp
+    const double E = -(FAST ? bl_log(w) : log(w));
+    const double d = 1.0 + kSmT * E;
+    const double q = FAST ? bl_div(right ? E : kSmT, right ? p.fz : d * d) : (right ? E / p.fz : kSmT / (d * d));
+    const double X = right ? kSmT + q : q;                                       // :171 / :98-99
+    const double aarg = -0.5 * (kSmT * E * E + p.Z * p.Z * X);
+    const double A = right ? 1.0 : (FAST ? bl_exp(aarg) : exp(aarg));
+    const double rarg = right ? -kSmPiSq * X : -(4.0 / kSmT) * d * d;            // log(a_1/a_0) - log 3
+    return pg1_decide<FAST>(s, X, A, rarg, u2, status);
   }
-  return finished;
+  if (right) {                                                                   // ZC == 2 only
+    const double E = -(FAST ? bl_log(w) : log(w));
+    const double X = kSmT + (FAST ? bl_div(E, p.fz) : E / p.fz);
+    return pg1_decide<FAST>(s, X, 1.0, -kSmPiSq * X, u2, status);
+  }
+  // mu <= t: inverse-Gaussian candidate from one normal, PolyaGamma.cpp:103-113
+  const double mu = 1.0 / p.Z;
+  double Y = qnorm(w);
+  Y *= Y;
+  const double half_mu = 0.5 * mu;
+  const double mu_Y = mu * Y;
+  const double X0 = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
+  const double pk = mu / (mu + X0);
+  const bool flip = u2 > pk;                                                     // :110
+  const double X = flip ? mu * mu / X0 : X0;
+  if (X > kSmT) {                                                                // :105
+    s.fresh = false;
+    return false;
+  }
+  double v = flip ? (u2 - pk) / (1.0 - pk) : u2 / pk;                            // the rest of u2
+  v = v < kSmWMin ? kSmWMin : v;
+  v = v > kSmWMax ? kSmWMax : v;
+  return pg1_decide<FAST>(s, X, 1.0, -4.0 / X, v, status);
 }
 
 // Sum of n PG(1, z) draws (PolyaGamma::draw(int n, z, r), :126-140; n < 1 -> 1 in the NTHROW
-// build) on the observation's own stream, as a per-lane loop over Philox blocks: two
-// transitions per block.  Lanes of a wave run it in lockstep; a lane that finishes early
-// idles until its wave does (the work-queue kernel in kernels_pg.hip avoids that wait).
+// build) on the observation's own stream, as a per-lane loop over Philox blocks.  Lanes of a
+// wave run it in lockstep; a lane that finishes early idles until its wave does (the work queue
+// of bl_pg1_queue.hpp avoids that wait).
 BL_HD double pg1_draw_n(int n, double z, uint64_t seed, uint64_t idx, uint32_t domain, uint32_t epoch, int& status)
 {
   if (n < 1) {
@@ -259,17 +225,13 @@ BL_HD double pg1_draw_n(int n, double z, uint64_t seed, uint64_t idx, uint32_t d
     status |= 2;
   }
   const Pg1Par p = pg1_par(z);
-  Pg1Lane s{SM_BRANCH, 0.0, 0.0};
+  Pg1Lane s{true, 0.0};
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t c0 = (uint32_t)idx, c1 = ctr1_of(idx, domain);
   double sum = 0.0;
   for (uint32_t blk = 0; blk < 4000000u; ++blk) {
     const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
-    if (pg1_advance(s, p, u52(o.x, o.y), status)) {
-      sum += 0.25 * s.X;
-      if (--n == 0) return sum;
-    }
-    if (pg1_advance(s, p, u52(o.z, o.w), status)) {
+    if (pg1_attempt(s, p, u52(o.x, o.y), u52(o.z, o.w), status)) {
       sum += 0.25 * s.X;
       if (--n == 0) return sum;
     }

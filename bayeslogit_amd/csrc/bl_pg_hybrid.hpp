@@ -20,6 +20,8 @@ __device__ __host__ __forceinline__ int pg_class(double b)
   return CLS_ZERO;
 }
 
+// One draw of class `cls` on the observation's stream.  CLS_DEVROYE (b = 1, 2) is not taken here: its
+// callers run pg1_draw_n (bl_pg1_sm.hpp), which owns the stream block by block.
 __device__ inline double pg_hybrid_class(int cls, double b, double z, Stream& r, int& status)
 {
   double x = 0.0;
@@ -30,7 +32,6 @@ __device__ inline double pg_hybrid_class(int cls, double b, double z, Stream& r,
       x = r.norm(m, sqrt(v));
     } break;
     case CLS_SP: sp_draw(x, b, z, r, 200, status); break;
-    case CLS_DEVROYE: x = pg_draw_devroye((int)b, z, r, status); break;
     case CLS_ALT: x = alt_draw(b, z, r, status); break;
     case CLS_GAMMA: x = pg_draw_sum_of_gammas(b, z, 200, r); break;
     default: x = 0.0;

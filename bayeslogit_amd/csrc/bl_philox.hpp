@@ -10,6 +10,13 @@ struct U4 { uint32_t x, y, z, w; };
 
 BL_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Keep only (k0, k1) live across the caller's loop: without this the ten bumped key pairs are
+  // hoisted as loop invariants (20 SGPRs), the draw kernels run out of SGPRs and the spilled ones
+  // come back through v_readlane -- VALU issue slots in a VALU-bound loop.  The bumps below are
+  // SALU adds, which issue beside other waves' VALU work.
+  asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;

@@ -95,6 +95,44 @@ __device__ __forceinline__ double dppmov_f64(double v)      // every lane has a 
 // kernels_pg.hip's k_rpg_devroye with X beta in place of a z vector.
 constexpr int kSuper = 512;
 
+// Phase 2 of the psi/omega pass as an out-of-line call: the draw's polynomial constants and state
+// then live in registers only while a chunk is being drawn, not across the streaming loop of
+// phase 1 (inlined, they were hoisted to kernel entry and starved that loop of registers: its
+// loads serialised behind scratch traffic).
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+  return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
+}
+template <typename T>
+__device__ __forceinline__ T* uniptr(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<uint64_t>(p))); }
+
+// (arguments of an out-of-line device function arrive in VGPRs; all but lt_mask are wave-uniform and
+// are moved back to SGPRs first.)  Returns the sampler status flags of the chunk.
+__device__ __attribute__((noinline)) int draw_chunk(const unsigned short* listA_, int nA_,
+                                                    const unsigned short* listB_, int nB_, const double* sZw_,
+                                                    const double* sMw_, const int* sNw_, double* w_, int64_t base_,
+                                                    uint64_t idx0_, uint32_t epoch_, uint32_t k0_, uint32_t k1_,
+                                                    uint64_t lt_mask)
+{
+  const unsigned short* listA = uniptr(listA_);
+  const unsigned short* listB = uniptr(listB_);
+  const double* sZw = uniptr(sZw_);
+  const double* sMw = uniptr(sMw_);
+  const int* sNw = uniptr(sNw_);
+  double* w = uniptr(w_);
+  const int nA = (int)uni32((uint32_t)nA_), nB = (int)uni32((uint32_t)nB_);
+  const int64_t base = (int64_t)uni64((uint64_t)base_);
+  const uint64_t idx0 = uni64(idx0_);
+  const uint32_t epoch = uni32(epoch_), k0 = uni32(k0_), k1 = uni32(k1_);
+  int st_flags = 0;
+  if (nA > 0)
+    devroye_queue<1, 2, int, true>(listA, nA, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+  if (nB > 0)
+    devroye_queue<2, 2, int, true>(listB, nB, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+  return st_flags;
+}
+
 template <int NB, int MODE>
 __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __restrict__ tX,
                                                             const double* __restrict__ nvec,
@@ -106,6 +144,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
 {
   __shared__ double sM[kBlock / 64][kSuper];
   __shared__ double sZ[kBlock / 64][kSuper];
+  __shared__ int sN[kBlock / 64][kSuper];
   __shared__ unsigned short sIdx[kBlock / 64][kSuper];   // class 1 from the front, class 2 from the back
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, c = lane & 15;
@@ -149,6 +188,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
           const Pg1Par p = pg1_par(psi);
           sZ[wave][slot] = psi;
           sM[wave][slot] = p.mass;
+          sN[wave][slot] = (int)nvec[base + slot];              // (int) n(i), Logit.hpp:287
           small = kSmTRecip > p.Z;              // PolyaGamma.cpp:87
           large = !small;
         } else {
@@ -166,13 +206,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
     if (MODE != blk::W_DRAW) { base += cnt; continue; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // phase 2: work queue per class; psi is read back from w[], omega overwrites it
-    if (nA > 0)
-      devroye_queue<1, 2, double>(&sIdx[wave][0], nA, sZ[wave], sM[wave], w, nvec, 1, base, idx0, epoch, k0, k1,
-                                     lt_mask, st_flags);
-    if (nB > 0)
-      devroye_queue<2, 2, double>(&sIdx[wave][kSuper - nB], nB, sZ[wave], sM[wave], w, nvec, 1, base, idx0, epoch,
-                                     k0, k1, lt_mask, st_flags);
+    // phase 2: work queue per class
+    st_flags |= draw_chunk(&sIdx[wave][0], nA, &sIdx[wave][kSuper - nB], nB, sZ[wave], sM[wave], sN[wave], w, base,
+                           idx0, epoch, k0, k1, lt_mask);
     __builtin_amdgcn_wave_barrier();
     base += cnt;
   }

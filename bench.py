@@ -80,18 +80,36 @@ def timed_steps(fn, steps, warmup, world, dev):
     return wall, kern_ms
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction),
+    or None.  bench.py cannot collect counters on itself; the summary is of this same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        e = d.get(kernel, {})
+        return e.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return None, None
+
+
 def cpu_baseline(draws_sample, ncores):
-    """The oracle (CPU restatement of the reference algorithm) on this box's host cores."""
+    """The oracle's literal restatement of the reference loops (PolyaGamma.cpp:151-202, call for
+    call) on this box's host cores."""
     sys.path.insert(0, os.path.join(HERE, "tests"))
     import oracle_lib as O
     rng = np.random.default_rng(20240001)
     n1 = min(draws_sample, 4_000_000)
     z = rng.uniform(0.0, 4.0, draws_sample)
     t0 = time.perf_counter()
-    O.rpg_devroye(n1, 1, z[:n1], 20240002)
+    O.rpg_devroye(n1, 1, z[:n1], 20240002, literal=True)
     one = n1 / (time.perf_counter() - t0)
     t0 = time.perf_counter()
-    O.rpg_devroye(draws_sample, 1, z, 20240002, threads=ncores)
+    O.rpg_devroye(draws_sample, 1, z, 20240002, threads=ncores, literal=True)
     allc = draws_sample / (time.perf_counter() - t0)
     return one, allc
 

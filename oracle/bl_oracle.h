@@ -69,8 +69,13 @@ double bl_p_igauss(double x, double mu, double lambda);
 double bl_pg_a(int n, double x);
 double bl_pg_mass_texpon(double Z);
 double bl_pg_rtigauss(double Z, bl_rng *r);
-double bl_pg_draw_like_devroye(double z, bl_rng *r);
+typedef struct { double Z, fz, mass, im, il; } bl_pg1_par;
+void   bl_pg1_par_of(bl_pg1_par *p, double z);
+int    bl_pg1_attempt(int *fresh, double *X, const bl_pg1_par *p, double u1, double u2);
+double bl_pg_draw_like_devroye(double z, bl_rng *r);           /* attempt form (= HIP path) */
 double bl_pg_draw_devroye(int n, double z, bl_rng *r);
+double bl_pg_draw_like_devroye_literal(double z, bl_rng *r);   /* the reference loops, literally */
+double bl_pg_draw_devroye_literal(int n, double z, bl_rng *r);
 double bl_pg_draw_sum_of_gammas(double b, double z, int trunc, bl_rng *r);
 double bl_pg_m1(double b, double z);
 double bl_pg_m2(double b, double z);
@@ -113,7 +118,7 @@ void bl_o_rpg_hybrid (double *x, const double *h, const double *z, int64_t num,
 void bl_o_rpg_hybrid_omp(double *x, const double *h, const double *z, int64_t num,
                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads);
 void bl_o_rpg_devroye_omp(double *x, const int *n, const double *z, int64_t num,
-                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads);
+                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads, int literal);
 int  bl_o_max_threads(void);
 
 /* ---- Gibbs / EM / combine (Code/C/Logit.hpp, MultLogit.hpp) ---- */

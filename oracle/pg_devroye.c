@@ -1,6 +1,18 @@
 /* pg_devroye.c -- oracle (test infrastructure, see bl_oracle.h).
  * Restates Code/C/PolyaGamma.{h,cpp}: the Devroye-style J*(1,z) sampler, the
  * truncated sum of gammas, and the closed-form moments.
+ *
+ * The PG(1,z) sampler appears twice:
+ *   - bl_pg_draw_like_devroye_literal / bl_pg_rtigauss: the reference loops line by line
+ *     (PolyaGamma.cpp:82-115, 151-202), one r.unif()/r.expon_rate()/r.norm() call where the
+ *     reference has one.  This is the CPU baseline bench.py times and the distribution every
+ *     other form is held to.
+ *   - bl_pg1_attempt / bl_pg_draw_like_devroye: the SAME proposals and acceptance events with
+ *     the uniforms of the stream spent two per attempt (one Philox block) and recycled, which
+ *     is the form the HIP kernels execute (bayeslogit_amd/csrc/bl_pg1_sm.hpp states the
+ *     derivation).  The HIP parity tests compare against this form draw for draw;
+ *     tests/test_oracle_pg.py pins it to the literal form's distribution and to the exact
+ *     PG(1,z) CDF.
  */
 #include "bl_oracle.h"
 #include <math.h>
@@ -75,7 +87,7 @@ double bl_pg_rtigauss(double Z, bl_rng *r)
 /* PolyaGamma::draw_like_devroye(Z, r) -- PolyaGamma.cpp:151-202.
  * mass_texpon(Z) is re-evaluated per proposal there (:170); it is a pure
  * function of Z so evaluating it once gives the identical value. */
-double bl_pg_draw_like_devroye(double Z, bl_rng *r)
+double bl_pg_draw_like_devroye_literal(double Z, bl_rng *r)
 {
   Z = fabs(Z) * 0.5;
   double fz = 0.125 * PG_PI * PG_PI + 0.5 * Z * Z;
@@ -103,6 +115,107 @@ double bl_pg_draw_like_devroye(double Z, bl_rng *r)
   }
 }
 
+/* ---- the attempt form (one Philox block = two uniforms per proposal attempt) ----
+ * Same events as the literal loops above:
+ *   right piece (u1 < mass, PolyaGamma.cpp:170-171): E = -log(u1/mass), X = t + E/fz;
+ *   left piece, mu > t (:87-101): E1 = -log(w), X = t/(1+t E1)^2; the pair test
+ *     E1^2 <= 2 E2/t (:95) holds with probability exp(-t E1^2/2) over E2 ~ Exp(1), and the
+ *     `unif <= alpha` test (:89,:100) with probability exp(-Z^2 X/2): both failures restart at
+ *     a new pair, so one uniform decides both: u2 <= A = exp(-t E1^2/2 - Z^2 X/2);
+ *   left piece, mu <= t (:103-113): Y = N(0,1)^2 from w by inversion, X0 as :107-109, the
+ *     reciprocal flip on u2 vs mu/(mu+X0) (:110-111), retry while X > t (:105);
+ *   accept (:175-199): first alternating-series test on the remainder of u2 (u2/A, or the
+ *     part of u2 the flip left), then the literal series on that same uniform.
+ * w = (u1 - mass)/(1 - mass) on the attempt that chose the left piece, u1 on retries. */
+#define PG1_WMIN 0x1.0p-53
+#define PG1_WMAX (1.0 - 0x1.0p-53)
+
+void bl_pg1_par_of(bl_pg1_par *p, double z)
+{
+  p->Z = fabs(z) * 0.5;                                   /* :154 */
+  p->fz = 0.125 * PG_PI * PG_PI + 0.5 * p->Z * p->Z;      /* :157 */
+  p->mass = bl_pg_mass_texpon(p->Z);
+  p->im = 1.0 / p->mass;
+  p->il = 1.0 / (1.0 - p->mass);
+}
+
+/* literal series PolyaGamma.cpp:175-199 with Y = u a_0(X); 1 = accept */
+static int pg1_series(double X, double u)
+{
+  double S = bl_pg_a(0, X);
+  double Y = u * S;
+  for (int n = 1; n < 100000; ++n) {
+    if (n % 2 == 1) {
+      S = S - bl_pg_a(n, X);
+      if (Y <= S) return 1;
+    } else {
+      S = S + bl_pg_a(n, X);
+      if (Y > S) return 0;
+    }
+  }
+  return 1;
+}
+
+static int pg1_decide(int *fresh, double *Xout, double X, double A, double rarg, double u2)
+{
+  if (u2 > A) { *fresh = 0; return 0; }
+  int ok = u2 <= A * (1.0 - 3.0 * exp(rarg));             /* U a_0 <= a_0 - a_1 */
+  if (!ok) ok = pg1_series(X, u2 / A);
+  *fresh = 1;
+  *Xout = X;
+  return ok;
+}
+
+/* one attempt; returns 1 when a draw completed (value 0.25 * *X) */
+int bl_pg1_attempt(int *fresh, double *X, const bl_pg1_par *p, double u1, double u2)
+{
+  const double t = PG_TRUNC;
+  int right = *fresh && u1 < p->mass;
+  double w = *fresh ? (right ? u1 * p->im : (u1 - p->mass) * p->il) : u1;
+  if (w < PG1_WMIN) w = PG1_WMIN;
+  if (w > PG1_WMAX) w = PG1_WMAX;
+  if (right) {
+    double E = -log(w);
+    double Xc = t + E / p->fz;
+    return pg1_decide(fresh, X, Xc, 1.0, -PG_PI * PG_PI * Xc, u2);
+  }
+  if (PG_TRUNC_RECIP > p->Z) {
+    double E1 = -log(w);
+    double d = 1.0 + t * E1;
+    double Xc = t / (d * d);
+    double A = exp(-0.5 * (t * E1 * E1 + p->Z * p->Z * Xc));
+    return pg1_decide(fresh, X, Xc, A, -(4.0 / t) * d * d, u2);
+  }
+  double mu = 1.0 / p->Z;
+  double Y = bl_qnorm(w);
+  Y *= Y;
+  double half_mu = 0.5 * mu;
+  double mu_Y = mu * Y;
+  double X0 = mu + half_mu * mu_Y - half_mu * sqrt(4 * mu_Y + mu_Y * mu_Y);
+  double pk = mu / (mu + X0);
+  int flip = u2 > pk;
+  double Xc = flip ? mu * mu / X0 : X0;
+  if (Xc > t) { *fresh = 0; return 0; }
+  double v = flip ? (u2 - pk) / (1.0 - pk) : u2 / pk;
+  if (v < PG1_WMIN) v = PG1_WMIN;
+  if (v > PG1_WMAX) v = PG1_WMAX;
+  return pg1_decide(fresh, X, Xc, 1.0, -4.0 / Xc, v);
+}
+
+/* PolyaGamma::draw_like_devroye(Z, r) in the attempt form (what the HIP path computes) */
+double bl_pg_draw_like_devroye(double z, bl_rng *r)
+{
+  bl_pg1_par p;
+  bl_pg1_par_of(&p, z);
+  int fresh = 1;
+  double X = 0.0;
+  for (;;) {
+    double u1 = bl_unif(r);
+    double u2 = bl_unif(r);
+    if (bl_pg1_attempt(&fresh, &X, &p, u1, u2)) return 0.25 * X;
+  }
+}
+
 /* PolyaGamma::draw(int n, z, r) -- PolyaGamma.cpp:126-140 (NTHROW build:
  * n < 1 is clamped to 1, Makevars:11). */
 double bl_pg_draw_devroye(int n, double z, bl_rng *r)
@@ -111,6 +224,15 @@ double bl_pg_draw_devroye(int n, double z, bl_rng *r)
   double sum = 0.0;
   for (int i = 0; i < n; ++i)
     sum += bl_pg_draw_like_devroye(z, r);
+  return sum;
+}
+
+double bl_pg_draw_devroye_literal(int n, double z, bl_rng *r)
+{
+  if (n < 1) n = 1;
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i)
+    sum += bl_pg_draw_like_devroye_literal(z, r);
   return sum;
 }
 

@@ -43,8 +43,10 @@ void bl_o_rpg_devroye(double *x, const int *n, const double *z, int64_t num,
   }
 }
 
+/* `literal` != 0: the reference loops call for call (bl_pg_draw_devroye_literal) instead of the
+ * attempt form; that is the CPU baseline bench.py reports. */
 void bl_o_rpg_devroye_omp(double *x, const int *n, const double *z, int64_t num,
-                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads)
+                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads, int literal)
 {
   (void)nthreads;
   /* thread-level strategy of Code/C/PolyaGammaOMP.h:61-71: dynamic schedule */
@@ -52,7 +54,8 @@ void bl_o_rpg_devroye_omp(double *x, const int *n, const double *z, int64_t num,
   for (int64_t i = 0; i < num; ++i) {
     bl_rng r;
     bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_DRAW, epoch);
-    x[i] = (n[i] != 0) ? bl_pg_draw_devroye(n[i], z[i], &r) : 0.0;
+    if (n[i] == 0) x[i] = 0.0;
+    else x[i] = literal ? bl_pg_draw_devroye_literal(n[i], z[i], &r) : bl_pg_draw_devroye(n[i], z[i], &r);
   }
 }
 

@@ -1,17 +1,68 @@
-"""Collapse rocprofv3 counter_collection CSVs (one row per dispatch and counter) into per-kernel means."""
-import csv, glob, sys, collections
+"""Collapse rocprofv3 counter_collection CSVs (one row per dispatch and counter) into per-kernel means.
+
+    python3 scripts/summarize_pmc.py TAG      # text to stdout + gpurun_out/pmc_summary_TAG.json
+
+The JSON holds, per kernel and per launch:
+  hbm_bytes_per_launch   = 2 x FETCH_SIZE + WRITE_SIZE.  rocprofv3 reports both in KiB; on gfx950
+                           FETCH_SIZE counts half the bytes of a 16-B/lane coalesced streaming read
+                           (MI355X_MICROARCH.md, HBM section), hence the factor 2.
+  valu_insts_per_launch  = SQ_INSTS_VALU (wave-level instructions)
+  gpu_cycles             = GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs)
+  valu_busy_frac         = SQ_ACTIVE_INST_VALU / (256 CUs x gpu_cycles): share of CU-cycles with a
+                           VALU instruction executing
+  valu_issue_frac_min    = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x gpu_cycles): issue-slot use if
+                           every instruction were full rate (fp64 transcendental-seed and 32-bit
+                           integer multiplies are slower, so this is a lower bound)
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
 tag = sys.argv[1]
+KEEP = ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce")
+SIMDS = 256 * 4
+summary = collections.defaultdict(dict)
 for kind in ("fetch", "write", "valu"):
     files = glob.glob(f"gpurun_out/pmc_{kind}_{tag}/**/*counter_collection.csv", recursive=True)
     if not files:
-        print(kind, "no counter file"); continue
+        print(kind, "no counter file")
+        continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     with open(files[0]) as f:
         for r in csv.DictReader(f):
-            name = r.get("Kernel_Name", "")[:90]
+            name = r.get("Kernel_Name", "")
             acc[name][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
     print(f"== {kind}: {files[0]}")
     for name, cs in sorted(acc.items()):
-        if not any(k in name for k in ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce")):
+        if not any(k in name for k in KEEP):
             continue
-        print(" ", name, {c: (sum(v) / len(v), len(v)) for c, v in cs.items()})
+        means = {c: sum(v) / len(v) for c, v in cs.items()}
+        print(" ", name[:90], {c: (m, len(cs[c])) for c, m in means.items()})
+        summary[name].update(means)
+
+out = {}
+for name, m in summary.items():
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "").strip()
+    short = short[:short.index("(")] if "(" in short else short
+    e = {}
+    if "FETCH_SIZE" in m:
+        e["fetch_bytes_corrected"] = 2.0 * m["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in m:
+        e["write_bytes"] = m["WRITE_SIZE"] * 1024.0
+    if "fetch_bytes_corrected" in e and "write_bytes" in e:
+        e["hbm_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+    if "SQ_INSTS_VALU" in m:
+        e["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
+        if m.get("GRBM_GUI_ACTIVE"):
+            cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+            e["gpu_cycles"] = cyc
+            e["valu_issue_frac_min"] = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * cyc)
+            if m.get("SQ_ACTIVE_INST_VALU"):
+                e["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] / (256.0 * cyc)
+        if m.get("SQ_WAVES"):
+            e["waves"] = m["SQ_WAVES"]
+    out[short] = e
+with open(f"gpurun_out/pmc_summary_{tag}.json", "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)

@@ -1,4 +1,4 @@
-// Host build of the kernels' PG(1,z) state machine (bayeslogit_amd/csrc/bl_pg1_sm.hpp) for
+// Host build of the kernels' PG(1,z) attempt body (bayeslogit_amd/csrc/bl_pg1_sm.hpp) for
 // CPU-side unit tests: the SAME header the HIP kernels inline, compiled as plain C++.
 // Test scaffolding only -- the shipped library never contains this object.
 #include "../../bayeslogit_amd/csrc/bl_pg1_sm.hpp"
@@ -17,20 +17,18 @@ void sm_rpg_devroye(double* x, const int* n, const double* z, long num, unsigned
 double sm_mass(double Z) { return bl::pg1_mass(Z, bl::kSmPiSq8 + 0.5 * Z * Z); }
 double sm_erfcx(double x) { return bl::erfcx_pos(x); }
 
-// transition census: how many uniforms a draw consumed (diagnostic for DESIGN.md)
-long sm_count_transitions(double z, long ndraws, unsigned long long seed)
+// attempt census: how many Philox blocks a draw consumed (diagnostic for DESIGN.md)
+long sm_count_attempts(double z, long ndraws, unsigned long long seed)
 {
   long total = 0;
   int st = 0;
   for (long i = 0; i < ndraws; ++i) {
     const bl::Pg1Par p = bl::pg1_par(z);
-    bl::Pg1Lane s{bl::SM_BRANCH, 0.0, 0.0};
+    bl::Pg1Lane s{true, 0.0};
     for (unsigned blk = 0;; ++blk) {
       const bl::U4 o = bl::philox4x32_10((unsigned)i, 0, 0, blk, (unsigned)seed, (unsigned)(seed >> 32));
       ++total;
-      if (bl::pg1_advance(s, p, bl::u52(o.x, o.y), st)) break;
-      ++total;
-      if (bl::pg1_advance(s, p, bl::u52(o.z, o.w), st)) break;
+      if (bl::pg1_attempt(s, p, bl::u52(o.x, o.y), bl::u52(o.z, o.w), st)) break;
     }
   }
   return total;

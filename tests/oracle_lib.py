@@ -74,7 +74,7 @@ def lib():
     sig("bl_sp_approx", c_d, c_d, c_d, c_d)
     sig("bl_sp_tangent_to_eta", None, c_d, c_d, c_d, c_dp, c_dp)
     sig("bl_o_rpg_devroye", None, c_dp, c_ip, c_dp, c_i64, c_u64, c_u32, c_u64)
-    sig("bl_o_rpg_devroye_omp", None, c_dp, c_ip, c_dp, c_i64, c_u64, c_u32, c_u64, C.c_int)
+    sig("bl_o_rpg_devroye_omp", None, c_dp, c_ip, c_dp, c_i64, c_u64, c_u32, c_u64, C.c_int, C.c_int)
     sig("bl_o_rpg_alt", None, c_dp, c_dp, c_dp, c_i64, c_u64, c_u32, c_u64)
     sig("bl_o_rpg_sp", None, c_dp, c_dp, c_dp, c_i64, c_ip, c_u64, c_u32, c_u64)
     sig("bl_o_rpg_gamma", None, c_dp, c_dp, c_dp, c_i64, C.c_int, c_u64, c_u32, c_u64)
@@ -126,12 +126,14 @@ def philox(ctr, key):
     return list(o)
 
 
-def rpg_devroye(num, n, z, seed, epoch=0, idx0=0, threads=0):
+def rpg_devroye(num, n, z, seed, epoch=0, idx0=0, threads=0, literal=False):
+    """literal=False: the attempt form (what the HIP path computes, draw for draw);
+    literal=True: the reference's loops call for call (same distribution, other stream use)."""
     n = np.ascontiguousarray(np.resize(np.asarray(n, dtype=np.int32), num))
     z = _f64(z, num)
     x = np.zeros(num)
-    if threads:
-        lib().bl_o_rpg_devroye_omp(dp(x), ip(n), dp(z), num, seed, epoch, idx0, threads)
+    if threads or literal:
+        lib().bl_o_rpg_devroye_omp(dp(x), ip(n), dp(z), num, seed, epoch, idx0, max(1, threads), int(literal))
     else:
         lib().bl_o_rpg_devroye(dp(x), ip(n), dp(z), num, seed, epoch, idx0)
     return x

@@ -57,6 +57,33 @@ def test_devroye_exact_cdf(oracle, z):
     assert np.all(x > 0)
 
 
+@pytest.mark.parametrize("z", [0.0, 0.5, 1.37, 3.0, 3.2, 8.0, -4.0, 40.0])
+def test_literal_reference_loops_exact_cdf(oracle, z):
+    """The call-for-call restatement of PolyaGamma.cpp:82-115,151-202 against the exact CDF."""
+    x = oracle.rpg_devroye(40000, 1, z, seed=int(abs(z) * 100) + 11, literal=True)
+    assert stats.kstest(x, lambda w: pgmath.pg1_cdf(w, z)).pvalue > 1e-3
+    assert np.all(x > 0)
+
+
+@pytest.mark.parametrize("z", [0.0, 1.0, 2.5, 3.1, 3.13, 4.5, 12.0])
+def test_attempt_form_equals_literal_form_in_distribution(oracle, z):
+    """bl_pg1_attempt (two uniforms per attempt, recycled: what the HIP kernels run) and the literal
+    reference loops: two-sample KS at 4e5 draws each (resolves CDF differences of ~3e-3), equal first two
+    moments within sampling error, and both within sampling error of the closed-form mean."""
+    n = 400000
+    a = oracle.rpg_devroye(n, 1, z, seed=1000 + int(z * 10))
+    b = oracle.rpg_devroye(n, 1, z, seed=2000 + int(z * 10), literal=True)
+    assert stats.ks_2samp(a, b).pvalue > 1e-3
+    var = pgmath.pg_var(1, z)
+    se = np.sqrt(var / n)
+    assert abs(a.mean() - pgmath.pg_mean(1, z)) < 5 * se and abs(b.mean() - pgmath.pg_mean(1, z)) < 5 * se
+    assert abs(a.var() - b.var()) < 5 * np.sqrt(2 * 12 * var * var / n)
+    # n > 1 sums use the same attempts back to back
+    a3 = oracle.rpg_devroye(100000, 3, z, seed=3000 + int(z * 10))
+    b3 = oracle.rpg_devroye(100000, 3, z, seed=4000 + int(z * 10), literal=True)
+    assert stats.ks_2samp(a3, b3).pvalue > 1e-3
+
+
 MOMENT_GRID = [(1, 0.0), (1, 2.0), (2, 1.0), (2, 6.0), (1.01, 0.7), (3.0, 0.0), (3.5, 1.0), (4.0, 2.0), (4.5, 0.5),
                (5.0, 3.0), (7.5, 0.5), (9.0, 1.0), (12.99, 4.0), (13.0, 0.1), (13.5, 1.0), (14.0, 1.0), (20.0, 0.0),
                (50.0, 2.0), (100.0, 5.0), (170.0, 0.1), (171.0, 1.0), (400.0, 3.0), (0.5, 1.0), (0.1, 0.0)]
