@@ -28,6 +28,7 @@ sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
+FP64_MFMA_PEAK_TFLOPS = 78.6    # AMD's MI355X figure for fp64 matrix (= the vector rate); MI355X_MICROARCH.md has no fp64 row
 BYTES_PER_DRAW = 16             # 8 B z in + 8 B x out (scalar shape)
 
 
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--gibbs-p", type=int, default=64)
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--c5", action="store_true", help="also time one GPU's shard of config C5 (12.5e6 x 256 per rank)")
+    ap.add_argument("--c5-sweeps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--mixed", action="store_true", help="also time config C3 (mixed shapes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
@@ -114,6 +117,96 @@ def cpu_baseline(draws_sample, ncores):
     return one, allc
 
 
+def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range):
+    """Gibbs sweeps/s on an N x P problem with rows sharded over the ranks: per sweep one pass over this
+    rank's rows (psi, omega, X' Omega X), one P*P all-reduce, the replicated P x P stage."""
+    lo, hi = shard_range(N, rank, world)
+    nl = hi - lo
+    X = torch.empty((nl, P), dtype=torch.float64, device=dev)
+    D.fill_norm(X, 0.0, 1.0 / P ** 0.5, 20240003, idx0=lo * P)
+    X[:, -1] = 1.0
+    bt = torch.empty(P, dtype=torch.float64, device=dev)
+    D.fill_norm(bt, 0.0, 1.0, 20240003, epoch=1)
+    bt.abs_()
+    bt[-1] = -0.5
+    y = torch.empty(nl, dtype=torch.float64, device=dev)
+    D.fill_logit_y(y, X, bt, 20240003, epoch=2, idx0=lo)
+    nn = torch.ones(nl, dtype=torch.float64, device=dev)
+    shard = D.GibbsShard(X, y, nn, seed=20240004, idx0=lo)
+    drv = DistGibbs(shard)
+    drv.setup(np.zeros(P), np.eye(P) * 0.01, np.zeros(P))
+    res = {}
+    for name, con in (("constrained", 1), ("unconstrained", 0)):
+        sw = [0]
+        ks, kb = [], []
+
+        def gstep():
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            shard.sweep_local(sw[0], None)
+            e1.record()
+            drv._all_reduce(shard.pp())
+            shard.draw_beta(sw[0], con)
+            e2.record()
+            ks.append((e0, e1))
+            kb.append((e1, e2))
+            sw[0] += 1
+
+        shard.set_beta(np.zeros(P))
+        for _ in range(3):
+            gstep()
+        ks.clear(), kb.clear()
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(sweeps):
+            gstep()
+        barrier_sync(world)
+        gw = max_over_ranks(time.perf_counter() - t0, world, dev)
+        sweep_ms = float(np.mean([p.elapsed_time(q) for p, q in ks]))
+        beta_ms = float(np.mean([p.elapsed_time(q) for p, q in kb]))
+        res[name] = {"sweeps_per_s": sweeps / gw, "ms_per_sweep": gw / sweeps * 1e3,
+                     "sweep_kernel_ms": sweep_ms, "allreduce_plus_beta_ms": beta_ms}
+    D.sync_status()
+    sk = res["constrained"]["sweep_kernel_ms"]
+    gb = 8.0 * nl * P / (sk * 1e-3) / 1e9
+    if P <= 64:
+        nbk = P // 16
+        kernels = f"k_psi_omega_nb<{nbk},0> + k_xwx_mfma<{nbk}> + k_reduce_fused<{nbk}>"
+        roof = {"kernel": kernels + " (one sweep: two passes over X)", "bound": "hbm", "achieved": gb,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": 8 * nl * P,
+                "note": "algorithmic bytes = X once (SURVEY 8d); the sweep reads X twice (DESIGN.md 4.3)"}
+        t1, src = pmc_traffic(f"k_psi_omega_nb<{nbk}, 0>")
+        t2, _ = pmc_traffic(f"k_xwx_mfma<{nbk}>")
+        roof["traffic"] = (t1 + t2) if (t1 and t2 and N == 10_000_000 and world == 1) else None
+        roof["traffic_source"] = src
+    else:
+        nbk = P // 16
+        tri = nbk * (nbk + 1) // 2
+        flops = 2.0 * nl * tri * 256                       # upper-triangle 16x16 blocks of the rank-N update
+        tf = flops / (sk * 1e-3) / 1e12
+        roof = {"kernel": f"k_psi_omega_nb<{nbk},0> + k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>", "bound": "mfma",
+                "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None, "algorithmic_flops_per_launch": flops,
+                "note": "whole sweep time (both passes) against the fp64 MFMA peak; X' Omega X alone is "
+                        "k_xwx_mfma_big in profiles/"}
+    roof["kernel_ms"] = sk
+    outg = {
+        "metric": "Gibbs sweeps/sec", "workload": f"{tag}: logit Gibbs N={N}, P={P}, fp64, omega not stored, "
+        f"rows sharded over {world} GPU(s), one P*P all-reduce per sweep",
+        "scaling": "strong" if tag == "C4" else "weak", "sweeps_timed": sweeps,
+        "value": res["constrained"]["sweeps_per_s"], "unit": "sweeps/s",
+        "beta_draw": "constrained = the reference's active draw (Logit.hpp:322-400); "
+                     "unconstrained = Logit.hpp:291-320",
+        **res,
+        "roofline": roof,
+        "beta_mean_head": [float(v) for v in shard.get_beta()[:4]],
+    }
+    shard.close()
+    del X, y, nn
+    return outg
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,6 +247,9 @@ def main():
     draws_per_s = n * world * a.steps / wall
     mean_x = x.mean().item()
     ach_gbs = BYTES_PER_DRAW * n / (kern_ms * 1e-3) / 1e9
+    c2_traffic, c2_traffic_src = pmc_traffic("k_rpg_devroye")
+    if n != 100_000_000:
+        c2_traffic = None                         # the committed counters are of the default workload
     out = {
         "metric": "PG draws/sec (millions)",
         "value": draws_per_s / 1e6,
@@ -176,7 +272,7 @@ def main():
             # reported as the contract asks, the VALU view is what actually bounds the kernel
             "bound": "valu",
             "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": c2_traffic, "traffic_source": c2_traffic_src,
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": BYTES_PER_DRAW * n,
             "draws_per_s_kernel": n / (kern_ms * 1e-3),
@@ -198,71 +294,12 @@ def main():
 
     # ---------------------------------------------------------------- C4: Gibbs sweeps
     if not a.no_gibbs:
-        N, P = a.gibbs_n, a.gibbs_p
-        lo, hi = shard_range(N, rank, world)
-        nl = hi - lo
-        X = torch.empty((nl, P), dtype=torch.float64, device=dev)
-        D.fill_norm(X, 0.0, 1.0 / P ** 0.5, 20240003, idx0=lo * P)
-        X[:, -1] = 1.0
-        bt = torch.empty(P, dtype=torch.float64, device=dev)
-        D.fill_norm(bt, 0.0, 1.0, 20240003, epoch=1)
-        bt.abs_()
-        bt[-1] = -0.5
-        y = torch.empty(nl, dtype=torch.float64, device=dev)
-        D.fill_logit_y(y, X, bt, 20240003, epoch=2, idx0=lo)
-        nn = torch.ones(nl, dtype=torch.float64, device=dev)
-        shard = D.GibbsShard(X, y, nn, seed=20240004, idx0=lo)
-        drv = DistGibbs(shard)
-        drv.setup(np.zeros(P), np.eye(P) * 0.01, np.zeros(P))
-        res = {}
-        for name, con in (("constrained", 1), ("unconstrained", 0)):
-            sw = [0]
-            ks, kb = [], []
-
-            def gstep():
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
-                shard.sweep_local(sw[0], None)
-                e1.record()
-                drv._all_reduce(shard.pp())
-                shard.draw_beta(sw[0], con)
-                e2.record()
-                ks.append((e0, e1))
-                kb.append((e1, e2))
-                sw[0] += 1
-
-            shard.set_beta(np.zeros(P))
-            for _ in range(3):
-                gstep()
-            ks.clear(), kb.clear()
-            barrier_sync(world)
-            t0 = time.perf_counter()
-            for _ in range(a.gibbs_sweeps):
-                gstep()
-            barrier_sync(world)
-            gw = max_over_ranks(time.perf_counter() - t0, world, dev)
-            sweep_ms = float(np.mean([p.elapsed_time(q) for p, q in ks]))
-            beta_ms = float(np.mean([p.elapsed_time(q) for p, q in kb]))
-            res[name] = {"sweeps_per_s": a.gibbs_sweeps / gw, "ms_per_sweep": gw / a.gibbs_sweeps * 1e3,
-                         "sweep_kernel_ms": sweep_ms, "allreduce_plus_beta_ms": beta_ms}
-        D.sync_status()
-        sk = res["constrained"]["sweep_kernel_ms"]
-        gb = 8.0 * nl * P / (sk * 1e-3) / 1e9
-        out["gibbs"] = {
-            "metric": "Gibbs sweeps/sec", "workload": f"C4: logit Gibbs N={N}, P={P}, fp64, omega not stored, "
-            f"rows sharded over {world} GPU(s), one P*P all-reduce per sweep",
-            "scaling": "strong", "sweeps_timed": a.gibbs_sweeps,
-            "value": res["constrained"]["sweeps_per_s"], "unit": "sweeps/s",
-            "beta_draw": "constrained = the reference's active draw (Logit.hpp:322-400); "
-                         "unconstrained = Logit.hpp:291-320",
-            **res,
-            "roofline": {"kernel": "k_psi_omega_nb<4,0> + k_xwx_mfma<4> + k_reduce_fused<4> (one sweep over X)", "bound": "hbm", "achieved": gb,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": sk, "algorithmic_bytes_per_launch": 8 * nl * P},
-            "beta_mean_head": [float(v) for v in shard.get_beta()[:4]],
-        }
-        shard.close()
-        del X, y, nn
+        out["gibbs"] = gibbs_bench(a.gibbs_n, a.gibbs_p, a.gibbs_sweeps, "C4", rank, world, dev, D, DistGibbs,
+                                   shard_range)
+    # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
+    if a.c5:
+        out["gibbs_c5"] = gibbs_bench(12_500_000 * world, 256, a.c5_sweeps, "C5 shard", rank, world, dev, D,
+                                      DistGibbs, shard_range)
 
     # ---------------------------------------------------------------- CPU baseline
     if rank == 0 and world == 1 and not a.no_cpu:

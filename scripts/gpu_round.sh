@@ -18,7 +18,7 @@ step() {  # name, timeout, command...
 : > gpurun_out/round.log
 step pytest_gpu 600 python -m pytest tests -m gpu -q
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
-step bench 400 python bench.py --mixed
+step bench 500 python bench.py --mixed --c5
 BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu"
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_*_$TAG
 step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py $BARGS
@@ -28,5 +28,6 @@ step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv
 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py $PARGS
 step pmc_valu 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu_$TAG -- python3 bench.py $PARGS
 python3 scripts/summarize_pmc.py $TAG > gpurun_out/pmc_summary_$TAG.txt 2>&1
+grep -h "^{" gpurun_out/bench.log | tail -1 > gpurun_out/bench_line_$TAG.json
 cat gpurun_out/pmc_summary_$TAG.txt | cut -c1-300
 exit 0
