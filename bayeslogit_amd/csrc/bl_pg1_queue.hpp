@@ -20,22 +20,32 @@
 
 namespace bl {
 
-template <int ZC, int ZSRC, typename NT, bool NLDS = false>
-__device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__ list, int cnt,
-                                              const double* __restrict__ z, const double* __restrict__ sM,
-                                              double* __restrict__ x, const NT* __restrict__ nvec, int nscalar,
-                                              int64_t base, uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
-                                              uint64_t lt_mask, int& st_flags)
-{
-  int next = 0;      // wave-uniform: first unstarted entry of the list
-  int q = -1;        // this lane's observation (slot in the chunk), -1 = idle
-  int nrem = 0;
-  uint32_t c0 = 0, c1 = 0, blk = 0;
+// A lane's in-flight observation.  Self-contained: once an observation has been started nothing of
+// the list it came from (index list, staged mass, z) is read again, so the state survives the caller
+// rebuilding those for its next chunk.
+struct Pg1Slot {
+  int64_t row = -1;         // index into x[] / global observation offset; -1 = idle
+  int nrem = 0;             // PG(1,z) draws still to add (PolyaGamma::draw(int n, ...), :126-140)
+  uint32_t c0 = 0, c1 = 0, blk = 0;   // Philox counter words of the observation's stream, next block
   double sum = 0.0;
   Pg1Par par{0.0, 1.0, 0.5, 2.0, 2.0};
   Pg1Lane sm{true, 0.0};
+};
+
+// Runs the queue over `list[0..cnt)`.  drain = false: return as soon as the list is exhausted, leaving
+// the lanes that are still inside a draw in flight in L (the caller comes back with the next list, or
+// with an empty list and drain = true); drain = true: run until every lane is idle.
+template <int ZC, int ZSRC, typename NT, bool NLDS = false>
+__device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const unsigned short* __restrict__ list,
+                                                  int cnt, const double* __restrict__ z,
+                                                  const double* __restrict__ sM, double* __restrict__ x,
+                                                  const NT* __restrict__ nvec, int nscalar, int64_t base,
+                                                  uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
+                                                  uint64_t lt_mask, int& st_flags)
+{
+  int next = 0;      // wave-uniform: first unstarted entry of the list
   for (;;) {
-    const bool idle = q < 0;
+    const bool idle = L.row < 0;
     const uint64_t im = __ballot(idle);
     if (im != 0 && next < cnt) {
       const int cand = next + __popcll(im & lt_mask);
@@ -43,34 +53,48 @@ __device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__
         const int slot = list[cand];
         int n = nvec ? (int)(NLDS ? nvec[slot] : nvec[base + slot]) : nscalar;      // (int) n(i), Logit.hpp:287
         if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }       // PolyaGamma.cpp:128-135 (NTHROW)
-        q = slot;
-        nrem = n;
-        par.Z = fabs(ZSRC == 2 ? z[slot] : ZSRC == 1 ? x[base + slot] : z[base + slot]) * 0.5;
-        par.mass = sM[slot];
-        pg1_par_finish(par);
+        L.row = base + slot;
+        L.nrem = n;
+        L.par.Z = fabs(ZSRC == 2 ? z[slot] : ZSRC == 1 ? x[base + slot] : z[base + slot]) * 0.5;
+        L.par.mass = sM[slot];
+        pg1_par_finish(L.par);
         const uint64_t idx = idx0 + (uint64_t)(base + slot);
-        c0 = (uint32_t)idx;
-        c1 = ctr1_of(idx, DOM_DRAW);
-        blk = 0;
-        sum = 0.0;
-        sm.fresh = true;
+        L.c0 = (uint32_t)idx;
+        L.c1 = ctr1_of(idx, DOM_DRAW);
+        L.blk = 0;
+        L.sum = 0.0;
+        L.sm.fresh = true;
       }
       next += __popcll(im);
     }
-    if (__ballot(q >= 0) == 0) {
+    if (__ballot(L.row >= 0) == 0) {
       if (next >= cnt) break;
       continue;
     }
-    if (q >= 0) {
-      const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
-      blk += 1;
-      if (pg1_attempt<true, ZC>(sm, par, u52(o.x, o.y), u52(o.z, o.w), st_flags)) {
-        sum += 0.25 * sm.X;
-        if (--nrem == 0) { x[base + q] = sum; q = -1; }
+    if (L.row >= 0) {
+      const U4 o = philox4x32_10(L.c0, L.c1, epoch, L.blk, k0, k1);
+      L.blk += 1;
+      if (pg1_attempt<true, ZC>(L.sm, L.par, u52(o.x, o.y), u52(o.z, o.w), st_flags)) {
+        L.sum += 0.25 * L.sm.X;
+        if (--L.nrem == 0) { x[L.row] = L.sum; L.row = -1; }
       }
-      if (blk > 4000000u) { st_flags |= ST_ITER_CAP; x[base + q] = sum; q = -1; }
+      if (L.blk > 4000000u) { st_flags |= ST_ITER_CAP; x[L.row] = L.sum; L.row = -1; }
     }
+    if (!drain && next >= cnt) break;
   }
+}
+
+// One list, start to finish (every lane idle on return).
+template <int ZC, int ZSRC, typename NT, bool NLDS = false>
+__device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__ list, int cnt,
+                                              const double* __restrict__ z, const double* __restrict__ sM,
+                                              double* __restrict__ x, const NT* __restrict__ nvec, int nscalar,
+                                              int64_t base, uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
+                                              uint64_t lt_mask, int& st_flags)
+{
+  Pg1Slot L;
+  devroye_queue_run<ZC, ZSRC, NT, NLDS>(L, true, list, cnt, z, sM, x, nvec, nscalar, base, idx0, epoch, k0, k1,
+                                        lt_mask, st_flags);
 }
 
 }  // namespace bl

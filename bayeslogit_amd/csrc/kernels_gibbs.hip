@@ -185,11 +185,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
       if (slot < cnt) {
         if (off) psi -= off[base + slot];
         if (MODE == blk::W_DRAW) {
-          const Pg1Par p = pg1_par(psi);
+          const double Z = fabs(psi) * 0.5;                     // PolyaGamma.cpp:154
           sZ[wave][slot] = psi;
-          sM[wave][slot] = p.mass;
+          sM[wave][slot] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);   // right for |psi|/2 < 1/t
           sN[wave][slot] = (int)nvec[base + slot];              // (int) n(i), Logit.hpp:287
-          small = kSmTRecip > p.Z;              // PolyaGamma.cpp:87
+          small = kSmTRecip > Z;                // PolyaGamma.cpp:87
           large = !small;
         } else {
           w[base + slot] = weight_of<MODE>(psi, nvec[base + slot], seed, 0, epoch, st_flags);
@@ -204,6 +204,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
       }
     }
     if (MODE != blk::W_DRAW) { base += cnt; continue; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the few |psi|/2 >= 1/t rows, now contiguous in their list, get the general mass
+    for (int i0 = 0; i0 < nB; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < nB) {
+        const int slot = sIdx[wave][kSuper - nB + i];
+        const double Z = fabs(sZ[wave][slot]) * 0.5;
+        sM[wave][slot] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // phase 2: work queue per class

@@ -13,67 +13,100 @@ constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond
 
 // ---------------------------------------------------------------- rpg_devroye
-// Wavefront work queue.  Each wave owns chunks of kChunk consecutive observations.
-//   phase 1 (all 64 lanes busy): coalesced load of z, proposal mass of every observation of
-//            the chunk (pg1_par: two Chebyshev sums) staged in LDS (z itself is re-read from L2
-//            when a lane starts the observation), and the observations
-//            COMPACTED BY CLASS into two index lists (ballot + prefix popcount): |z|/2 < 1/t
-//            and |z|/2 >= 1/t take different left-piece samplers (PolyaGamma.cpp:87 vs :103),
-//            i.e. different states of the machine;
-//   phase 2: once per class, the lane-uniform state machine of bl_pg1_sm.hpp compiled for that
-//            class only.  A lane whose draw has completed takes the next unstarted observation
-//            of the list (idle lanes found with __ballot, numbered with a prefix popcount), so
-//            the wave keeps all lanes on the same short transition body instead of waiting for
-//            its slowest rejection loop or executing another class's code.
+// Wavefront work queue, one launch per sampler class: |z|/2 < 1/t and |z|/2 >= 1/t take different
+// left-piece samplers (PolyaGamma.cpp:87 vs :103); a launch contains the code of ONE class and
+// skips the observations of the other, so the light class runs at 3 waves/SIMD without carrying
+// the heavy one's registers.  Each wave owns chunks of kChunk consecutive observations.
+//   phase 1 (all 64 lanes busy): coalesced load of z, the observations of this launch's class
+//            COMPACTED into an index list (ballot + prefix popcount) and their proposal mass staged
+//            in LDS (class 1: a 12-term polynomial in z^2 computed in the same sweep; class 2: two
+//            Chebyshev sums, evaluated over the compacted list so that all lanes are busy); z and
+//            n are staged too, so a lane starting an observation waits on nothing from HBM;
+//   phase 2: the attempt body of bl_pg1_sm.hpp under the work queue of bl_pg1_queue.hpp.  A lane
+//            whose draw has completed takes the next unstarted observation of the list (idle lanes
+//            found with __ballot, numbered with a prefix popcount); lanes still inside a draw when
+//            the list runs out stay IN FLIGHT while the wave builds the next chunk's list, so the
+//            queue drains once per launch, not once per chunk.
 // The stream belongs to the observation, so which lane draws it, and when, does not change the
 // result.
-constexpr int kChunk = 1024;   // 16 observations per lane: the queue's drain tail is ~8% of a chunk
+constexpr int kChunk = 512;
 
-__global__ __launch_bounds__(kBlock, 3) void k_rpg_devroye(double* __restrict__ x, const int* __restrict__ nvec,
-                                                           int nscalar, const double* __restrict__ z, int64_t num,
-                                                           uint64_t seed, uint32_t epoch, uint64_t idx0,
-                                                           int* __restrict__ status)
+template <int CLS>
+__global__ __launch_bounds__(kBlock, CLS == 1 ? 3 : 2) void k_rpg_devroye(double* __restrict__ x,
+                                                                          const int* __restrict__ nvec, int nscalar,
+                                                                          const double* __restrict__ z, int64_t num,
+                                                                          uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                                          int* __restrict__ status)
 {
   __shared__ double sM[kBlock / 64][kChunk];
-  __shared__ unsigned short sIdx[kBlock / 64][kChunk];   // class 1 from the front, class 2 from the back
+  __shared__ double sZ[kBlock / 64][kChunk];
+  __shared__ int sN[kBlock / 64][kChunk];
+  __shared__ unsigned short sIdx[kBlock / 64][kChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const int64_t nchunks = (num + kChunk - 1) / kChunk;
   int st_flags = 0;
+  Pg1Slot L;           // this lane's in-flight observation
   for (int64_t ch = (int64_t)blockIdx.x * (kBlock / 64) + wave; ch < nchunks; ch += (int64_t)gridDim.x * (kBlock / 64)) {
     const int64_t base = ch * kChunk;
     const int cnt = (int)((num - base) < kChunk ? (num - base) : kChunk);
-    int nA = 0, nB = 0;   // wave-uniform list lengths
-    for (int k0s = 0; k0s < cnt; k0s += 64) {
-      const int k = k0s + lane;
-      bool small = false, large = false;
-      if (k < cnt) {
-        const int n = nvec ? nvec[base + k] : nscalar;
-        if (n == 0) {
-          x[base + k] = 0.0;                         // LogitWrapper.cpp:74-77
-        } else {
-          const Pg1Par p = pg1_par(z[base + k]);
-          sM[wave][k] = p.mass;
-          small = kSmTRecip > p.Z;                   // PolyaGamma.cpp:87
-          large = !small;
-        }
+    int nL = 0;        // wave-uniform list length
+    // all of the chunk's loads are issued before the first is used (one 512-byte load in flight per
+    // wave made this phase latency-bound)
+    constexpr int LB = CLS == 1 ? 4 : 8;   // loads in flight per lane (register budget of the class)
+#pragma unroll 1
+    for (int j0 = 0; j0 < kChunk / 64; j0 += LB) {
+      if (j0 * 64 >= cnt) break;
+      double zk[LB];
+      int nk[LB];
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int k = (j0 + j) * 64 + lane;
+        zk[j] = k < cnt ? z[base + k] : 0.0;
+        nk[j] = nvec ? (k < cnt ? nvec[base + k] : 0) : nscalar;
       }
-      const uint64_t ma = __ballot(small), mb = __ballot(large);
-      if (small) sIdx[wave][nA + __popcll(ma & lt_mask)] = (unsigned short)k;
-      if (large) sIdx[wave][kChunk - 1 - (nB + __popcll(mb & lt_mask))] = (unsigned short)k;
-      nA += __popcll(ma);
-      nB += __popcll(mb);
+#pragma unroll
+      for (int j = 0; j < LB; ++j) {
+        const int k = (j0 + j) * 64 + lane;
+        bool mine = false;
+        if (k < cnt) {
+          const int n = nk[j];
+          if (n == 0) {
+            if (CLS == 1) x[base + k] = 0.0;           // LogitWrapper.cpp:74-77
+          } else {
+            const double Z = fabs(zk[j]) * 0.5;        // PolyaGamma.cpp:154
+            mine = (kSmTRecip > Z) == (CLS == 1);      // PolyaGamma.cpp:87
+            sZ[wave][k] = zk[j];
+            sN[wave][k] = n;
+            if (CLS == 1 && mine) sM[wave][k] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);
+          }
+        }
+        const uint64_t mm = __ballot(mine);
+        if (mine) sIdx[wave][nL + __popcll(mm & lt_mask)] = (unsigned short)k;
+        nL += __popcll(mm);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (nA > 0)
-      devroye_queue<1, 0, int>(&sIdx[wave][0], nA, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask, st_flags);
-    if (nB > 0)
-      devroye_queue<2, 0, int>(&sIdx[wave][kChunk - nB], nB, z, sM[wave], x, nvec, nscalar, base, idx0, epoch, k0, k1, lt_mask,
-                       st_flags);
+    if (CLS == 2) {
+      for (int i0 = 0; i0 < nL; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < nL) {
+          const int k = sIdx[wave][i];
+          const double Z = fabs(sZ[wave][k]) * 0.5;
+          sM[wave][k] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    devroye_queue_run<CLS, 2, int, true>(L, false, &sIdx[wave][0], nL, sZ[wave], sM[wave], x, sN[wave], 1, base, idx0,
+                                         epoch, k0, k1, lt_mask, st_flags);
     __builtin_amdgcn_wave_barrier();
   }
+  devroye_queue_run<CLS, 2, int, true>(L, true, nullptr, 0, nullptr, nullptr, x, nullptr, 1, 0, idx0, epoch, k0, k1,
+                                       lt_mask, st_flags);
   if (st_flags) atomicOr(status, st_flags);
 }
 
@@ -238,7 +271,11 @@ int bl_rpg_devroye_dev(double* x, const int* n_vec, int n_scalar, const double* 
   if (int rc = check_args(x, z, num)) return rc;
   if (num == 0) return BL_OK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rpg_devroye, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, n_vec,
+  // one launch per sampler class, each sized to its resident grid (3 resp. 2 workgroups per CU)
+  const int64_t wg_chunks = (num + 4 * kChunk - 1) / (4 * kChunk);
+  hipLaunchKernelGGL(k_rpg_devroye<1>, dim3(blh::grid_for(wg_chunks, 1, 256 * 3)), dim3(kBlock), 0, s, x, n_vec,
+                     n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
+  hipLaunchKernelGGL(k_rpg_devroye<2>, dim3(blh::grid_for(wg_chunks, 1, 256 * 2)), dim3(kBlock), 0, s, x, n_vec,
                      n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
   BL_HIP_TRY(hipGetLastError());
   return BL_OK;

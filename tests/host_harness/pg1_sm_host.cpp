@@ -14,7 +14,8 @@ void sm_rpg_devroye(double* x, const int* n, const double* z, long num, unsigned
   *status = st;
 }
 
-double sm_mass(double Z) { return bl::pg1_mass(Z, bl::kSmPiSq8 + 0.5 * Z * Z); }
+double sm_mass(double Z) { return bl::pg1_par(2.0 * Z).mass; }   // the class dispatch the kernels use
+double sm_mass_general(double Z) { return bl::pg1_mass(Z, bl::kSmPiSq8 + 0.5 * Z * Z); }
 double sm_erfcx(double x) { return bl::erfcx_pos(x); }
 
 // attempt census: how many Philox blocks a draw consumed (diagnostic for DESIGN.md)

@@ -18,12 +18,14 @@ LIB = os.path.join(HERE, "host_harness", "libpg1_sm_host.so")
 def harness():
     hdrs = [os.path.join(HERE, "..", "bayeslogit_amd", "csrc", f)
             for f in ("bl_pg1_sm.hpp", "bl_erfcx.hpp", "bl_philox.hpp", "bl_portable.hpp", "bl_fastmath.hpp",
-                      "bl_qnorm.hpp")]
+                      "bl_qnorm.hpp", "bl_masspoly.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in hdrs + [SRC]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB, SRC, "-lm"])
     H = C.CDLL(LIB)
     H.sm_mass.restype = C.c_double
     H.sm_mass.argtypes = [C.c_double]
+    H.sm_mass_general.restype = C.c_double
+    H.sm_mass_general.argtypes = [C.c_double]
     H.sm_erfcx.restype = C.c_double
     H.sm_erfcx.argtypes = [C.c_double]
     H.sm_count_attempts.restype = C.c_long
@@ -41,7 +43,8 @@ def test_mass_matches_reference_formula(harness, oracle):
     L = oracle.lib()
     for Z in np.concatenate([np.linspace(0, 3, 601), [1.5624, 1.5625, 1.5626, 5, 10, 20, 30]]):
         ref = L.bl_pg_mass_texpon(Z)                      # literal PolyaGamma.cpp:65-80
-        assert abs(harness.sm_mass(Z) - ref) <= 2e-14 * ref
+        assert abs(harness.sm_mass(Z) - ref) <= 2e-14 * ref           # polynomial below 1/t, erfcx form above
+        assert abs(harness.sm_mass_general(Z) - ref) <= 2e-14 * ref   # erfcx form everywhere
     assert harness.sm_mass(100.0) == 0.0
 
 
