@@ -754,6 +754,8 @@ __device__ __forceinline__ double wave_min(double v)
   return v;
 }
 
+__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg);
+
 __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
@@ -840,6 +842,14 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
   if (!wg_chol_lower(S, P, &bad)) {     // L = chol(S,'L'), in place
     __syncthreads();
     if (t == 0) atomicOr(a.status, 8);
+    return;
+  }
+  if (P <= 256) {
+    // z = L^{-1}(beta_prev - mP), then the coordinate sweeps with their random input pre-generated
+    for (int j = t; j < P; j += (int)blockDim.x) zz[j] = a.beta_prev[j] - mP[j];
+    __syncthreads();
+    wg_solve_L(S, zz, P);
+    constrained_wide_prepare(a, S, A);      // U in A is dead: A takes 1/L.  k_beta_sweeps follows.
     return;
   }
   // LDS layout: beta, z (P doubles each), perm (P ints), then L (P*P) when it fits.  The vectors
@@ -1485,6 +1495,191 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (row) a.beta_out[lane] = bj;
   if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
 }
+
+// ---- constrained coordinate sweeps for 64 < P <= 256 (Logit.hpp:368-399), same design as k_beta64's:
+// every random input generated up front by the whole workgroup (a tnorm call owns nine uniforms whatever
+// its bounds), the P^2 moves on ONE wavefront, lane l owning rows l + 64 r (beta in registers), bounds by a
+// per-lane fold then the DPP max/min, the four tnorm attempts on lanes 0-3.  L stays in global memory
+// (512 KB at P = 256: it lives in L2) next to its elementwise reciprocal; the columns of a move are fetched two
+// moves ahead, the records of the next scan are staged into LDS by the idle waves.
+// Scratch layout in a.work after the generic stage's 2 P^2 + 2 P doubles: records, then swap targets.
+__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg)
+{
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);
+  const uint32_t per_scan = (uint32_t)(10 * P - 1);
+  for (int e = t; e < P * (P - 1); e += nthr) {
+    const int k = e / (P - 1), i = e % (P - 1);
+    const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
+    swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);       // r.flat(i, P), Logit.hpp:375
+  }
+  for (int e = t; e < P * P; e += nthr) {
+    const int k = e / P, i = e % P;
+    const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+    double* R = rec + (size_t)e * kRec;
+    for (int m = 0; m < 4; ++m) {
+      const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+      const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+      const double lua = log(ua);
+      R[4 * m] = ua;
+      R[4 * m + 1] = lua;
+      R[4 * m + 2] = log(ub);
+      R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+    }
+    R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+    R[17] = R[18] = R[19] = 0.0;
+  }
+  // 1/L elementwise, off the serial loop, split by the sign test of Logit.hpp:384-391: Rlo holds 1/L where
+  // L > 0 (those rows bound the move from below), Rhi where L < 0, NaN elsewhere -- above the diagonal
+  // (L = 0: rows j < c are outside the loop of :383) and in row P-1 (the loop stops at P-2).  v_max_f64 /
+  // v_min_f64 return the other operand for a NaN, so the sweeps need no compares or selects.
+  double* Rhi = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;
+  const double nan = __builtin_nan("");
+  for (int e = t; e < P * P; e += nthr) {
+    const int j = e % P;
+    const double l = Lg[e];
+    const double r = 1.0 / l;
+    Rg[e] = (l > 0.0 && j < P - 1) ? r : nan;
+    Rhi[e] = (l < 0.0 && j < P - 1) ? r : nan;
+  }
+}
+
+// The sweeps themselves: one 4-wave workgroup (512 registers per lane available: the pipeline's register
+// sets do not spill), launched behind k_beta on the same stream.  Reads L, 1/L, z from k_beta's scratch.
+template <int RPL>
+__global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
+{
+  extern __shared__ double lds[];
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const int nrec = P * kRec;
+  const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
+  const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
+  const double* zz = a.work + 2 * (size_t)P * P + P;               // z
+  double* recL = lds;                                  // 2 x (P records): the scan in progress / next
+  double* sz = recL + 2 * nrec;                        // z
+  unsigned char* ptab = reinterpret_cast<unsigned char*>(sz + P);   // ptab[k][i]: coordinate of move i of scan k
+  double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);
+  const double* __restrict__ Rh = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;   // 1/L where L < 0, else NaN
+  for (int j = t; j < P; j += nthr) sz[j] = zz[j];
+  __syncthreads();
+  // scan permutations: each scan's swaps on the identity (thread k), then composed in scan order
+  if (t < P) {
+    unsigned char* sg = ptab + t * P;
+    for (int i = 0; i < P; ++i) sg[i] = (unsigned char)i;
+    for (int i = 0; i < P - 1; ++i) {
+      const int j = swp[t * (P - 1) + i];
+      const unsigned char tmp = sg[i];
+      sg[i] = sg[j];
+      sg[j] = tmp;
+    }
+  }
+  __syncthreads();
+  for (int k = 1; k < P; ++k) {
+    int v = 0;
+    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
+    __syncthreads();
+    if (t < P) ptab[k * P + t] = (unsigned char)v;
+    __syncthreads();
+  }
+
+  const int lane = t & 63;
+  const bool serial = t < 64;
+  const double inf = __builtin_huge_val();
+  double bj[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int j = lane + 64 * r;
+    bj[r] = (serial && j < P) ? a.beta_prev[j] : 0.0;
+  }
+  for (int e = t; e < nrec; e += nthr) recL[e] = rec[e];
+  __syncthreads();
+  for (int k = 0; k < P; ++k) {
+    const double* Rk = recL + (k & 1) * nrec;
+    if (!serial) {
+      if (k + 1 < P) {
+        double* Rn = recL + ((k + 1) & 1) * nrec;
+        const double* src = rec + (size_t)(k + 1) * nrec;
+        for (int e = t - 64; e < nrec; e += nthr - 64) Rn[e] = src[e];
+      }
+    } else {
+      const int g4 = (lane < 5 ? lane : 0) * 4;
+      const unsigned char* pk = ptab + k * P;
+      // software pipeline, kDepth register sets used round-robin (no copies: a copy would wait on the
+      // load): the columns of L and 1/L of move i + kDepth are requested as soon as move i has used its
+      // set; z and the record come from LDS one move ahead
+      constexpr int kDepth = 4;
+      double lq[kDepth][RPL], rlo[kDepth][RPL], rhi[kDepth][RPL];
+      int jr[RPL];           // this lane's rows, clamped to P-1 (a clamped row sees NaN reciprocals: no effect)
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) jr[r] = (lane + 64 * r) < P ? lane + 64 * r : P - 1;
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        const size_t co = (size_t)__builtin_amdgcn_readfirstlane((int)pk[u < P ? u : P - 1]) * P;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          lq[u][r] = (Lg + co)[jr[r]];
+          rlo[u][r] = (Rg + co)[jr[r]];
+          rhi[u][r] = (Rh + co)[jr[r]];
+        }
+      }
+      int c_n = pk[0];
+      double z1_n = sz[c_n];
+      double q0 = Rk[g4], q1 = Rk[g4 + 1], q2 = Rk[g4 + 2], q3 = Rk[g4 + 3];
+      for (int i0 = 0; i0 < P; i0 += kDepth) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+          const int i = i0 + u;
+          if (i < P) {
+            const int c = __builtin_amdgcn_readfirstlane(c_n);
+            const double r0 = q0, r1 = q1, r2 = q2, r3 = q3;
+            const double z1 = z1_n;
+            double lo = -inf, hi = inf, l1[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+              l1[r] = lq[u][r];
+              lo = vmax64(lo, z1 - bj[r] * rlo[u][r]);      // NaN (row not in the lower set) leaves lo as it is
+              hi = vmin64(hi, z1 - bj[r] * rhi[u][r]);
+            }
+            if (i + kDepth < P) {
+              const size_t co = (size_t)__builtin_amdgcn_readfirstlane((int)pk[i + kDepth]) * P;
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                lq[u][r] = (Lg + co)[jr[r]];
+                rlo[u][r] = (Rg + co)[jr[r]];
+                rhi[u][r] = (Rh + co)[jr[r]];
+              }
+            }
+            if (i + 1 < P) {
+              c_n = pk[i + 1];
+              const double* Rn = Rk + (i + 1) * kRec + g4;
+              q0 = Rn[0];
+              q1 = Rn[1];
+              q2 = Rn[2];
+              q3 = Rn[3];
+            }
+            wave_maxmin(lo, hi);
+            const double z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+            const double dz = z2 - z1;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) bj[r] += l1[r] * dz;    // L(j, c) = 0 for j < c: rows above c do not move
+            if (lane == 0) sz[c] = z2;
+            if (i + 1 < P) z1_n = sz[__builtin_amdgcn_readfirstlane(c_n)];   // after the store above in program order
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (serial) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int j = lane + 64 * r;
+      if (j < P) a.beta_out[j] = bj[r];
+    }
+  }
+}
 #undef L_
 
 __global__ void k_maxabsdiff(const double* a, const double* b, int P, double* out)
@@ -1699,7 +1894,9 @@ void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_o
 
 size_t beta_work_doubles(int P)
 {
-  const size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
+  size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
+  if (P > 64 && P <= 256)    // constrained_sweeps_wide: tnorm records + swap targets after the dense stage's matrices
+    generic += (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P;   // + the second reciprocal matrix
   const size_t small = (size_t)P * P * kRec + 2 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
   return generic > small ? generic : small;
 }
@@ -1718,11 +1915,26 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   size_t lds = 0;
   if (mode == B_CONSTRAINED) {
     const size_t pp = (size_t)a.P * a.P * 8;
-    lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8 + (pp <= 128 * 1024 ? pp : 0);
+    if (a.P <= 256)   // constrained_sweeps_wide: two scans of records, z, byte permutation table
+      lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;
+    else
+      lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8 + (pp <= 128 * 1024 ? pp : 0);
   }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), lds, s, a, mode);
+  const bool wide = mode == B_CONSTRAINED && a.P <= 256;
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), wide ? 0 : lds, s, a, mode);
+  if (wide) {
+    if (a.P <= 128) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<2>, dim3(1), dim3(kBlock), lds, s, a);
+    } else {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a);
+    }
+  }
 }
 
 void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s)

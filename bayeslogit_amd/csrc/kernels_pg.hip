@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock, CLS == 1 ? 3 : 2) void k_rpg_devroye(double
 }
 
 // ------------------------------------------------ rpg_alt / rpg_sp / rpg_gamma
-__global__ __launch_bounds__(kBlock) void k_rpg_alt(double* __restrict__ x, const double* __restrict__ h,
+__global__ __launch_bounds__(kBlock, 3) void k_rpg_alt(double* __restrict__ x, const double* __restrict__ h,
                                                     const double* __restrict__ z, int64_t num, uint64_t seed,
                                                     uint32_t epoch, uint64_t idx0, int* __restrict__ status)
 {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_rpg_alt(double* __restrict__ x, cons
   if (st) atomicOr(status, st);
 }
 
-__global__ __launch_bounds__(kBlock) void k_rpg_sp(double* __restrict__ x, const double* __restrict__ h,
+__global__ __launch_bounds__(kBlock, 3) void k_rpg_sp(double* __restrict__ x, const double* __restrict__ h,
                                                    const double* __restrict__ z, int64_t num,
                                                    int* __restrict__ iter, uint64_t seed, uint32_t epoch,
                                                    uint64_t idx0, int* __restrict__ status)
