@@ -66,7 +66,16 @@ SIGNATURES = {
     "bl_gibbs_beta_ptr": (c_vp, [c_vp]),
     "bl_gibbs_get_beta": (C.c_int, [c_vp, c_dp]),
     "bl_gibbs_run": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_dp, c_vp]),
+    "bl_gibbs_run_stream": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_vp, c_vp]),
 }
+
+
+class GibbsStats(C.Structure):
+    """bl_gibbs_stats of include/bayeslogit_hip.h"""
+    _fields_ = [("beta_mean_host", c_dp), ("beta_var_host", c_dp), ("w_mean_dev", c_vp), ("w_var_dev", c_vp)]
+
+
+W_NONE, W_LAST, W_ALL = 0, 1, 2
 
 
 class BayesLogitError(RuntimeError):

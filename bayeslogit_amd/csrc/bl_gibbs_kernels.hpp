@@ -85,4 +85,8 @@ void launch_matvec(double* dst, const double* M, const double* v, int P, hipStre
 // ty is U x N column-major (U = 1 for the binomial case).  Returns new N in *N_out.
 int combine_rows(double* ty, double* tX, double* n, int64_t N, int P, int U, int64_t* N_out, hipStream_t s);
 
+// running moments over the samples of a chain: (mean, M2) += sample number `count` (1-based); finish: M2 -> variance
+void launch_welford(const double* x, double* mean, double* m2, int64_t n, int64_t count, hipStream_t s);
+void launch_welford_finish(double* m2, int64_t n, int64_t count, hipStream_t s);
+
 }  // namespace blk

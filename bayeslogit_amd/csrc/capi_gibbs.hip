@@ -280,6 +280,109 @@ int bl_gibbs_run(bl_gibbs* h, int samp, int burn, int constrain, double* beta_ou
   return blh::collect_status(h->stream);
 }
 
+// Streaming / thinning / on-device moments; same chain as bl_gibbs_run.
+int bl_gibbs_run_stream(bl_gibbs* h, int samp, int burn, int constrain, int thin, double* beta_out_host, int w_mode,
+                        double* w_out, const bl_gibbs_stats* stats)
+{
+  if (int rc = valid(h)) return rc;
+  if (samp < 1 || burn < 0 || thin < 1 || w_mode < BL_W_NONE || w_mode > BL_W_ALL ||
+      (w_mode != BL_W_NONE && !w_out) ||
+      (stats && ((stats->w_mean_dev == nullptr) != (stats->w_var_dev == nullptr)))) {
+    blh::set_error("bl_gibbs_run_stream: bad arguments");
+    return BL_ERR_ARG;
+  }
+  const int P = h->P;
+  const int64_t N = h->N;
+  const int nkeep = (samp + thin - 1) / thin;
+  const bool wstats = stats && stats->w_mean_dev;
+  const bool bstats = stats && (stats->beta_mean_host || stats->beta_var_host);
+  blh::DevBuf<double> hist, bmom, ring;
+  hipError_t e = hist.alloc((size_t)P * nkeep);
+  if (e == hipSuccess && bstats) e = bmom.alloc(2 * (size_t)P);
+  int K = 0;
+  hipStream_t cs = nullptr;
+  std::vector<hipEvent_t> ev_done, ev_copied;
+  if (e == hipSuccess && w_mode == BL_W_ALL) {
+    const int64_t per = N > 0 ? N : 1;
+    int64_t k = (int64_t)(256ll << 20) / (8 * per);                 // ring of about 256 MB, at least two slots
+    K = (int)(k < 2 ? 2 : (k > samp ? samp : k));
+    if (K < 1) K = 1;
+    e = ring.alloc((size_t)per * K);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    ev_done.resize(K);
+    ev_copied.resize(K);
+    for (int i = 0; e == hipSuccess && i < K; ++i) {
+      e = hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming);
+    }
+  }
+  if (e == hipSuccess && bstats) e = hipMemsetAsync(bmom.p, 0, sizeof(double) * 2 * P, h->stream);
+  if (e == hipSuccess && wstats && N > 0) {
+    e = hipMemsetAsync(stats->w_mean_dev, 0, sizeof(double) * N, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(stats->w_var_dev, 0, sizeof(double) * N, h->stream);
+  }
+  int rc = e == hipSuccess ? bl_gibbs_set_bp_local(h) : BL_ERR_HIP;
+  if (rc == BL_OK) rc = bl_gibbs_finish_bp(h);
+  if (rc == BL_OK && hipMemsetAsync(h->beta, 0, sizeof(double) * P, h->stream) != hipSuccess) rc = BL_ERR_HIP;
+  uint32_t sweep = 0;
+  double* burn_slot = w_mode == BL_W_ALL ? ring.p : (w_mode == BL_W_LAST ? w_out : nullptr);
+  for (int m = 0; rc == BL_OK && m < burn; ++m, ++sweep) {
+    rc = bl_gibbs_sweep_local(h, sweep, burn_slot);
+    if (rc == BL_OK) rc = bl_gibbs_draw_beta(h, sweep, constrain);
+  }
+  for (int m = 0; rc == BL_OK && e == hipSuccess && m < samp; ++m, ++sweep) {
+    const int slot = K > 0 ? m % K : 0;
+    double* wdst = nullptr;
+    if (w_mode == BL_W_ALL) {
+      wdst = ring.p + (size_t)slot * (N > 0 ? N : 1);
+      if (m >= K) e = hipStreamWaitEvent(h->stream, ev_copied[slot], 0);     // the slot's previous copy has left
+    } else if (w_mode == BL_W_LAST) {
+      wdst = w_out;
+    }
+    if (e != hipSuccess) break;
+    rc = bl_gibbs_sweep_local(h, sweep, wdst);
+    if (rc != BL_OK) break;
+    const double* wsrc = wdst ? wdst : h->wscr;                               // where this sweep's omega is
+    if (wstats) blk::launch_welford(wsrc, stats->w_mean_dev, stats->w_var_dev, N, m + 1, h->stream);
+    if (w_mode == BL_W_ALL && N > 0) {
+      e = hipEventRecord(ev_done[slot], h->stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev_done[slot], 0);
+    }
+    rc = bl_gibbs_draw_beta(h, sweep, constrain);                             // enqueued before the host blocks in the copy
+    if (rc != BL_OK) break;
+    if (bstats) blk::launch_welford(h->beta, bmom.p, bmom.p + P, P, m + 1, h->stream);
+    if (m % thin == 0 && e == hipSuccess)
+      e = hipMemcpyAsync(hist.p + (size_t)(m / thin) * P, h->beta, sizeof(double) * P, hipMemcpyDeviceToDevice, h->stream);
+    if (w_mode == BL_W_ALL && N > 0 && e == hipSuccess) {
+      e = hipMemcpyAsync(w_out + (size_t)m * N, wdst, sizeof(double) * N, hipMemcpyDeviceToHost, cs);
+      if (e == hipSuccess) e = hipEventRecord(ev_copied[slot], cs);
+    }
+  }
+  if (rc == BL_OK && e == hipSuccess && wstats) blk::launch_welford_finish(stats->w_var_dev, N, samp, h->stream);
+  if (rc == BL_OK && e == hipSuccess && bstats) blk::launch_welford_finish(bmom.p + P, P, samp, h->stream);
+  if (rc == BL_OK && e == hipSuccess && beta_out_host)
+    e = hipMemcpyAsync(beta_out_host, hist.p, sizeof(double) * (size_t)P * nkeep, hipMemcpyDeviceToHost, h->stream);
+  if (rc == BL_OK && e == hipSuccess && stats && stats->beta_mean_host)
+    e = hipMemcpyAsync(stats->beta_mean_host, bmom.p, sizeof(double) * P, hipMemcpyDeviceToHost, h->stream);
+  if (rc == BL_OK && e == hipSuccess && stats && stats->beta_var_host)
+    e = hipMemcpyAsync(stats->beta_var_host, bmom.p + P, sizeof(double) * P, hipMemcpyDeviceToHost, h->stream);
+  hipError_t e2 = hipStreamSynchronize(h->stream);
+  if (cs) {
+    hipError_t e3 = hipStreamSynchronize(cs);
+    if (e2 == hipSuccess) e2 = e3;
+    (void)hipStreamDestroy(cs);
+  }
+  for (auto& ev : ev_done) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ev_copied) if (ev) (void)hipEventDestroy(ev);
+  if (e == hipSuccess) e = e2;
+  if (e != hipSuccess) {
+    blh::set_error(std::string("bl_gibbs_run_stream: ") + hipGetErrorString(e));
+    return BL_ERR_HIP;
+  }
+  if (rc != BL_OK) return rc;
+  return blh::collect_status(h->stream);
+}
+
 // ================================================================ .C boundary
 // gibbs(), LogitWrapper.cpp:176-234
 void gibbs(double* wp, double* betap, double* yp, double* tXp, double* np, double* m0p, double* P0p, int* N, int* P,
@@ -289,11 +392,10 @@ void gibbs(double* wp, double* betap, double* yp, double* tXp, double* np, doubl
   const int64_t n = *N;
   const int p = *P;
   const uint64_t seed = blh::global_seed() ^ ((uint64_t)blh::next_epoch() << 40);
-  blh::DevBuf<double> dX, dy, dn, dw;
+  blh::DevBuf<double> dX, dy, dn;
   hipError_t e = dX.alloc((size_t)n * p);
   if (e == hipSuccess) e = dy.alloc(n);
   if (e == hipSuccess) e = dn.alloc(n);
-  if (e == hipSuccess) e = dw.alloc((size_t)n * *samp);
   if (e == hipSuccess) e = dX.upload(tXp);
   if (e == hipSuccess) e = dy.upload(yp);
   if (e == hipSuccess) e = dn.upload(np);
@@ -306,12 +408,9 @@ void gibbs(double* wp, double* betap, double* yp, double* tXp, double* np, doubl
   int rc = bl_gibbs_create(&h, n, p, 0, seed, nullptr);
   if (rc == BL_OK) rc = bl_gibbs_set_data(h, dX.p, dy.p, dn.p);
   if (rc == BL_OK) rc = bl_gibbs_set_prior(h, m0p, P0p);
-  if (rc == BL_OK) rc = bl_gibbs_run(h, *samp, *burn, blh::global_constrain(), betap, dw.p);
-  if (rc == BL_OK || rc == BL_ERR_SAMPLER) {
-    e = dw.download(wp);
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    if (e != hipSuccess) blh::set_error(std::string("gibbs: ") + hipGetErrorString(e));
-  } else {
+  // w (N x samp, caller-owned host memory) is filled sweep by sweep through a device ring
+  if (rc == BL_OK) rc = bl_gibbs_run_stream(h, *samp, *burn, blh::global_constrain(), 1, betap, BL_W_ALL, wp, nullptr);
+  if (rc != BL_OK && rc != BL_ERR_SAMPLER) {
     printf("Error: %s\n", bl_last_error());
     printf("Aborting Gibbs sampler.\n");
   }

@@ -1682,6 +1682,28 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
 }
 #undef L_
 
+// Running moments of a chain: Welford update of (mean, M2) with the count-th sample x.
+__global__ __launch_bounds__(kBlock) void k_welford(const double* __restrict__ x, double* __restrict__ mean,
+                                                    double* __restrict__ m2, int64_t n, double count)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const double inv = 1.0 / count;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const double v = x[i], m = mean[i];
+    const double d = v - m;
+    const double mn = m + d * inv;
+    mean[i] = mn;
+    m2[i] += d * (v - mn);
+  }
+}
+// M2 -> sample variance M2 / (count - 1) (0 when count < 2)
+__global__ __launch_bounds__(kBlock) void k_welford_finish(double* __restrict__ m2, int64_t n, double count)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const double s = count > 1.0 ? 1.0 / (count - 1.0) : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) m2[i] *= s;
+}
+
 __global__ void k_maxabsdiff(const double* a, const double* b, int P, double* out)
 {
   __shared__ double sm[kBlock];
@@ -1935,6 +1957,21 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
       hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a);
     }
   }
+}
+
+void launch_welford(const double* x, double* mean, double* m2, int64_t n, int64_t count, hipStream_t s)
+{
+  if (n <= 0) return;
+  int64_t g = (n + kBlock - 1) / kBlock;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_welford, dim3((int)g), dim3(kBlock), 0, s, x, mean, m2, n, (double)count);
+}
+void launch_welford_finish(double* m2, int64_t n, int64_t count, hipStream_t s)
+{
+  if (n <= 0) return;
+  int64_t g = (n + kBlock - 1) / kBlock;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_welford_finish, dim3((int)g), dim3(kBlock), 0, s, m2, n, (double)count);
 }
 
 void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s)

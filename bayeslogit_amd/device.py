@@ -183,6 +183,36 @@ class GibbsShard:
                                            _ptr(w_out)), "bl_gibbs_run")
         return beta
 
+    def run_stream(self, samp, burn, constrain=1, thin=1, store_w="none", moments=False):
+        """The chain of run() with streamed / reduced outputs (bl_gibbs_run_stream).
+        store_w: "none" | "last" (device tensor, N) | "all" (host numpy, samp x N, streamed through a ring).
+        moments: also return running mean / variance of beta (numpy) and omega (device tensors) over the
+        samp sweeps, accumulated on the device.  Returns a dict."""
+        import ctypes as C
+        import numpy as np
+        nkeep = (samp + thin - 1) // thin
+        beta = np.zeros((nkeep, self.P))
+        out = {"beta": beta}
+        mode = {"none": _lib.W_NONE, "last": _lib.W_LAST, "all": _lib.W_ALL}[store_w]
+        wptr = None
+        if store_w == "last":
+            out["w"] = torch.empty(self.N, dtype=torch.float64, device="cuda")
+            wptr = _ptr(out["w"])
+        elif store_w == "all":
+            out["w"] = np.zeros((samp, self.N))
+            wptr = out["w"].ctypes.data_as(C.c_void_p)
+        st = None
+        if moments:
+            out["beta_mean"], out["beta_var"] = np.zeros(self.P), np.zeros(self.P)
+            out["w_mean"] = torch.empty(self.N, dtype=torch.float64, device="cuda")
+            out["w_var"] = torch.empty(self.N, dtype=torch.float64, device="cuda")
+            st = _lib.GibbsStats(out["beta_mean"].ctypes.data_as(_lib.c_dp), out["beta_var"].ctypes.data_as(_lib.c_dp),
+                                 _ptr(out["w_mean"]), _ptr(out["w_var"]))
+        _lib.check(_lib.lib().bl_gibbs_run_stream(self.h, samp, burn, int(constrain), int(thin),
+                                                  beta.ctypes.data_as(_lib.c_dp), mode, wptr,
+                                                  C.byref(st) if st is not None else None), "bl_gibbs_run_stream")
+        return out
+
 
 class _DevView:
     """float64 torch tensor over a raw device pointer (no copy, no ownership)."""

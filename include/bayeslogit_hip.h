@@ -160,6 +160,25 @@ int  bl_gibbs_get_beta(bl_gibbs *h, double *beta_host);
 int  bl_gibbs_run(bl_gibbs *h, int samp, int burn, int constrain,
                   double *beta_out_host, double *w_out_dev);
 
+/* The same chain with the outputs streamed, thinned or reduced on the device, for sizes where the
+ * N x samp array of Logit.hpp:434-444 / LogitWrapper.R:223,239-241 cannot be materialised.
+ *   w_mode BL_W_NONE : omega is never stored (w_out ignored)
+ *          BL_W_LAST : w_out is a DEVICE buffer of N doubles holding the last sweep's omega
+ *          BL_W_ALL  : w_out is a HOST buffer, N x samp column-major, filled sweep by sweep through a
+ *                      small device ring while the next sweep runs (device memory O(N), not O(N samp))
+ *   thin >= 1        : beta_out_host receives every thin-th sample: P x ceil(samp / thin)
+ *   stats (or NULL)  : moments over all samp sweeps, accumulated on the device (Welford):
+ *                      beta_mean/beta_var HOST buffers of P doubles (or NULL);
+ *                      w_mean/w_var DEVICE buffers of N doubles (or NULL, both or neither).
+ * Draws are those of bl_gibbs_run for the same handle seed. */
+enum { BL_W_NONE = 0, BL_W_LAST = 1, BL_W_ALL = 2 };
+typedef struct {
+  double *beta_mean_host, *beta_var_host;
+  double *w_mean_dev, *w_var_dev;
+} bl_gibbs_stats;
+int  bl_gibbs_run_stream(bl_gibbs *h, int samp, int burn, int constrain, int thin,
+                         double *beta_out_host, int w_mode, double *w_out, const bl_gibbs_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -212,6 +212,47 @@ def test_mlogit_matches_oracle(gpu, oracle):
     assert yc["X"].shape == (50, P) and np.all(yc["n"] == 2)
 
 
+@pytest.mark.parametrize("constrain", [0, 1])
+def test_streamed_thinned_and_reduced_outputs(gpu, constrain):
+    """bl_gibbs_run_stream against bl_gibbs_run on the same seed: omega streamed to the host
+    through the device ring is bit-identical to the N x samp device array, store_w="last" is its last column,
+    thinning keeps every thin-th beta, and the on-device Welford moments of beta and omega equal numpy's over
+    the stored samples."""
+    N, P, samp, burn = 3000, 16, 13, 4
+    X, y, n = synth(N, P, 5, nmax=2)
+    P0 = np.eye(P) * 0.1
+
+    def fresh():
+        g = shard_of(X, y, n, gpu, seed=99)
+        g.set_prior(np.zeros(P), P0)
+        return g
+
+    g = fresh()
+    wdev = torch.empty((samp, N), dtype=torch.float64, device=gpu)
+    beta = g.run(samp, burn, constrain, wdev)
+    g.close()
+    g = fresh()
+    out = g.run_stream(samp, burn, constrain, thin=1, store_w="all", moments=True)
+    g.close()
+    assert np.array_equal(out["beta"], beta)
+    assert np.array_equal(out["w"], wdev.cpu().numpy())
+    assert np.allclose(out["beta_mean"], beta.mean(0), rtol=1e-12, atol=1e-14)
+    assert np.allclose(out["beta_var"], beta.var(0, ddof=1), rtol=1e-10, atol=1e-16)
+    wn = wdev.cpu().numpy()
+    assert np.allclose(out["w_mean"].cpu().numpy(), wn.mean(0), rtol=1e-12, atol=0)
+    assert np.allclose(out["w_var"].cpu().numpy(), wn.var(0, ddof=1), rtol=1e-9, atol=1e-18)
+    g = fresh()
+    out3 = g.run_stream(samp, burn, constrain, thin=3, store_w="last")
+    g.close()
+    assert np.array_equal(out3["beta"], beta[::3])
+    assert torch.equal(out3["w"], wdev[-1])
+    g = fresh()
+    outn = g.run_stream(samp, burn, constrain, thin=1, store_w="none", moments=True)
+    g.close()
+    assert np.array_equal(outn["beta"], beta) and np.array_equal(outn["beta_mean"], out["beta_mean"])
+    assert torch.equal(outn["w_mean"], out["w_mean"])
+
+
 def test_full_size_C4_properties(gpu):
     """BASELINE C4 shape (N = 1e7, P = 64): one sweep at full size.  Size-independent checks: PP exactly
     symmetric, trace(PP) = sum_i omega_i |x_i|^2 and PP 1 = X'(omega * (X 1)) recomputed by torch, E[omega]
