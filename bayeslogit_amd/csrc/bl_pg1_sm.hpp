@@ -161,6 +161,11 @@ BL_HD bool pg1_any(bool need)
 template <bool FAST>
 BL_HD bool pg1_decide(Pg1Lane& s, double X, double A, double rarg, double u2, int& status)
 {
+  if (!(X == X)) {                   // z = NaN: the reference's loops fall through with X = NaN (:105, :191)
+    s.fresh = true;
+    s.X = X;
+    return true;
+  }
   if (u2 > A) {                      // left piece only (A = 1 on the right): a new pair / candidate
     s.fresh = false;
     return false;

@@ -158,6 +158,7 @@ static int pg1_series(double X, double u)
 
 static int pg1_decide(int *fresh, double *Xout, double X, double A, double rarg, double u2)
 {
+  if (!(X == X)) { *fresh = 1; *Xout = X; return 1; }     /* z = NaN: the reference loops fall through with NaN */
   if (u2 > A) { *fresh = 0; return 0; }
   int ok = u2 <= A * (1.0 - 3.0 * exp(rarg));             /* U a_0 <= a_0 - a_1 */
   if (!ok) ok = pg1_series(X, u2 / A);

@@ -157,6 +157,21 @@ def test_edge_cases(gpu, oracle):
     assert bl._lib.lib().bl_last_sampler_flags() & 2
     agree(x.cpu().numpy(), oracle.rpg_devroye(2, [-2, 1], [1.0, 1.0], 4))
     D.sync_status()   # flags were cleared by the failed sync
+    # chunk boundaries of the per-class work queue (512 observations per wave chunk), both classes mixed,
+    # shapes > 1, huge |z| (proposal mass underflows to 0), z = NaN (the reference falls through with NaN)
+    rng = np.random.default_rng(8)
+    for n in (511, 512, 513, 2047, 4100):
+        z = rng.normal(0, 3, n)
+        z[::97] = 60.0
+        z[5] = np.nan
+        shp = rng.integers(1, 4, n).astype(np.int32)
+        x = D.rpg_devroye(dev_t(z, gpu), dev_t(shp, gpu, torch.int32), seed=9, idx0=123456789012)
+        D.sync_status()
+        xo = oracle.rpg_devroye(n, shp, z, 9, 0, 123456789012)
+        xg = x.cpu().numpy()
+        assert np.isnan(xg[5]) and np.isnan(xo[5])
+        keep = np.arange(n) != 5
+        agree(xg[keep], xo[keep])
 
 
 def test_determinism_and_shard_invariance(gpu):
