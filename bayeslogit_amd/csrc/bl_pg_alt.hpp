@@ -50,10 +50,10 @@ __device__ inline double alt_w_left(double trunc, double h, double z)
 }
 
 // w_right, PolyaGammaAlt.cpp:70-75
-__device__ inline double alt_w_right(double trunc, double h, double z)
+__device__ inline double alt_w_right(double trunc, double h, double z, double lgam_h)
 {
   const double lambda_z = kPiSq * 0.125 + 0.5 * z * z;
-  return exp(h * log(kHalfPi / lambda_z)) * (1.0 - p_gamma_rate(trunc, h, lambda_z));
+  return exp(h * log(kHalfPi / lambda_z)) * (1.0 - p_gamma_rate(trunc, h, lambda_z, lgam_h));
 }
 
 // rtigauss(h, z, trunc, r), PolyaGammaAlt.cpp:77-97
@@ -95,11 +95,11 @@ __device__ inline double alt_draw_abridged(double h, double z, Stream& r, int ma
   const int idx = (int)floor((h - 1.0) * 100.0);
   const double trunc = kTruncSchedule[idx];
   const double rate_z = 0.125 * kPi * kPi + 0.5 * z * z;
+  const double lgam_h = lgamma(h);
   const double weight_left = alt_w_left(trunc, h, z);
-  const double weight_right = alt_w_right(trunc, h, z);
+  const double weight_right = alt_w_right(trunc, h, z, lgam_h);
   const double prob_right = weight_right / (weight_right + weight_left);
   const double coef1_h = exp(h * kLog2 - 0.5 * log(2.0 * kPi));
-  const double lgam_h = lgamma(h);
   double ratio = 1.0;
 
   for (int trial = 0; trial < 10000; ++trial) {

@@ -24,11 +24,11 @@ __device__ inline double log_pnorm(double x)
 __device__ __forceinline__ double pnorm(double x) { return 0.5 * erfc(-x * kSqrtHalf); }
 
 // P(a, x): series below a+1, modified-Lentz continued fraction for Q above.
-__device__ inline double reg_lower_gamma(double a, double x)
+// lg = lgamma(a), passed in by callers that need it themselves.
+__device__ inline double reg_lower_gamma(double a, double x, double lg)
 {
   if (!(x > 0.0)) return 0.0;
   if (isinf(x)) return 1.0;
-  const double lg = lgamma(a);
   if (x < a + 1.0) {
     double ap = a, del = 1.0 / a, sum = del;
     for (int n = 0; n < 2000; ++n) {
@@ -59,7 +59,11 @@ __device__ inline double reg_lower_gamma(double a, double x)
 
 __device__ __forceinline__ double p_gamma_rate(double x, double shape, double rate)
 {
-  return reg_lower_gamma(shape, rate * x);
+  return reg_lower_gamma(shape, rate * x, lgamma(shape));
+}
+__device__ __forceinline__ double p_gamma_rate(double x, double shape, double rate, double lgam_shape)
+{
+  return reg_lower_gamma(shape, rate * x, lgam_shape);
 }
 
 // Inverse-Gaussian CDF, second term in log space.

@@ -998,9 +998,13 @@ __device__ __forceinline__ double tnorm_lanes(double r0, double r1, double r2, d
     flip = hi < 0.0;
     a = flip ? -hi : lo;
     b = flip ? -lo : hi;
-    const double alpha = 0.5 * (a + sqrt(a * a + 4.0));
-    if (b - a > 1.0 / alpha) {
-      x = a - r1 / alpha;
+    // this branch is on the dependent chain of every coordinate move: the short sqrt / divide forms
+    // (<= 1 ulp from the IEEE ones)
+    const double s4 = a * a + 4.0;
+    const double alpha = 0.5 * (a + (s4 < 1e300 ? bl_sqrt(s4) : sqrt(s4)));
+    const double ialpha = bl_div(1.0, alpha);
+    if (b - a > ialpha) {
+      x = a - r1 * ialpha;
       const double d = x - alpha;
       ok = x <= b && r2 <= -0.5 * d * d;
     } else {

@@ -40,4 +40,6 @@ long sm_count_attempts(double z, long ndraws, unsigned long long seed)
 extern "C" {
 double fm_log(double x) { return bl::bl_log(x); }
 double fm_exp(double x) { return bl::bl_exp(x); }
+double fm_sqrt(double x) { return bl::bl_sqrt(x); }
+double fm_div(double a, double b) { return bl::bl_div(a, b); }
 }

@@ -100,3 +100,11 @@ def test_fastmath_log_exp_accuracy(harness):
     xs = np.concatenate([rng.uniform(-40, 0, 3000), rng.uniform(-700, 700, 1000), rng.uniform(-1e-3, 1e-3, 500), [0.0]])
     assert max(ulps(harness.fm_exp(x), mp.exp(mp.mpf(x))) for x in xs) < 1.5
     assert harness.fm_exp(-800.0) == 0.0 and np.isinf(harness.fm_exp(710.0))
+    # (host build: the hardware estimates are replaced by exact seeds, so this checks the iteration algebra)
+    harness.fm_sqrt.restype = C.c_double
+    harness.fm_sqrt.argtypes = [C.c_double]
+    harness.fm_div.restype = C.c_double
+    harness.fm_div.argtypes = [C.c_double, C.c_double]
+    xs = np.concatenate([rng.uniform(4, 50, 2000), 10.0 ** rng.uniform(-200, 200, 500)])
+    assert max(ulps(harness.fm_sqrt(x), mp.sqrt(mp.mpf(x))) for x in xs) < 1.01
+    assert max(ulps(harness.fm_div(1.0, x), 1 / mp.mpf(x)) for x in xs) < 1.01
