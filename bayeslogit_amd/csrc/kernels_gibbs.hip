@@ -9,8 +9,9 @@
 // (A single-pass version that kept each 64-row tile in registers between the two uses was
 // built first and measured 5.8 ms/sweep at N=1e7, P=64: it is confined to one wave per SIMD
 // and the draw's dependent fp64 chains then run at latency, not throughput.  DESIGN.md.)
-//   * generic fallbacks for shapes the MFMA path does not take (P not a multiple of 16, or
-//     P > 64): k_psi_omega + k_xwx_tiles.
+//   * any P <= 256 runs on these kernels: P <= 64 on the register-tile pair (columns padded to 16 NB with
+//     zeros in registers when P is not a multiple of 16, 8-byte masked loads), 64 < P <= 256 on the LDS-tile
+//     kernel k_xwx_mfma_big (128 or 256 columns); generic kernels (k_psi_omega + k_xwx_tiles) above that.
 //   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
 #include "bl_gibbs_kernels.hpp"
@@ -55,12 +56,23 @@ __device__ __host__ __forceinline__ int colmap(int q, int c)
 
 // One group = 4 consecutive rows; lane (k = lane>>4, c = lane&15) takes row k of the group and
 // the NB columns colmap(q, c).  ok = row in range (out-of-range rows read row 0 and are zeroed).
-template <int NB>
-__device__ __forceinline__ void load_group(double (&xg)[NB], const double* __restrict__ tX, int64_t row, bool ok, int c)
+// Pa = the matrix's real number of columns (row stride).  EXACT (Pa == 16 NB): 16-byte vector loads;
+// otherwise the same lane-to-column assignment with 8-byte loads, columns >= Pa read as zero.  (A
+// compile-time switch: with a runtime test the exact path carried the other one's registers.)
+template <int NB, bool EXACT>
+__device__ __forceinline__ void load_group(double (&xg)[NB], const double* __restrict__ tX, int64_t row, bool ok, int c,
+                                           int Pa)
 {
   constexpr int P = 16 * NB;
-  const double* p = tX + (size_t)(ok ? row : 0) * P;
-  if (NB == 1) {
+  const double* p = tX + (size_t)(ok ? row : 0) * (size_t)(EXACT ? P : Pa);
+  if (!EXACT) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int col = colmap<NB>(q, c);
+      const double v = p[col < Pa ? col : Pa - 1];
+      xg[q] = (ok && col < Pa) ? v : 0.0;
+    }
+  } else if (NB == 1) {
     const double v = p[c];
     xg[0] = ok ? v : 0.0;
   } else if (NB == 3) {
@@ -133,12 +145,12 @@ __device__ __attribute__((noinline)) int draw_chunk(const unsigned short* listA_
   return st_flags;
 }
 
-template <int NB, int MODE>
+template <int NB, int MODE, bool EXACT>
 __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __restrict__ tX,
                                                             const double* __restrict__ nvec,
                                                             const double* __restrict__ beta,
                                                             const double* __restrict__ off,
-                                                            double* __restrict__ w, int64_t N, int chunk,
+                                                            double* __restrict__ w, int64_t N, int Pa, int chunk,
                                                             uint64_t seed, uint32_t epoch, uint64_t idx0,
                                                             int* __restrict__ status)
 {
@@ -153,7 +165,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
   int st_flags = 0;
   double bq[NB];
 #pragma unroll
-  for (int q = 0; q < NB; ++q) bq[q] = beta[colmap<NB>(q, c)];
+  for (int q = 0; q < NB; ++q) {
+    const int col = colmap<NB>(q, c);
+    bq[q] = (EXACT || col < Pa) ? beta[col] : 0.0;
+  }
 
   // this wave's contiguous row range, cut into chunks
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
       for (int g = 0; g < 16; ++g) {
         const int64_t row = base + t0 + 4 * g + k;
         double xg[NB];
-        load_group<NB>(xg, tX, row, row < N, c);
+        load_group<NB, EXACT>(xg, tX, row, row < N, c, Pa);
         double part = 0.0;
 #pragma unroll
         for (int q = 0; q < NB; ++q) part += xg[q] * bq[q];
@@ -234,9 +249,9 @@ struct Acc {
   v4d a[NB * (NB + 1) / 2];
 };
 
-template <int NB>
+template <int NB, bool EXACT>
 __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict__ tX, const double* __restrict__ w,
-                                                        int64_t N, double* __restrict__ partial)
+                                                        int64_t N, int Pa, double* __restrict__ partial)
 {
   constexpr int NBLK = NB * (NB + 1) / 2;
   __shared__ double red[2][NBLK * 4][64];
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int64_t row = tile * 64 + 4 * g + k;
-      load_group<NB>(x[g], tX, row, row < N, c);
+      load_group<NB, EXACT>(x[g], tX, row, row < N, c, Pa);
     }
     const int64_t myrow = tile * 64 + 4 * c + k;
     const double omega = myrow < N ? w[myrow] : 0.0;
@@ -310,9 +325,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
 // take the i <= j half of diagonal blocks, mirror: PP is exactly symmetric.
 template <int NB>
 __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict__ partial, int nparts,
-                                                       double* __restrict__ PP)
+                                                       double* __restrict__ PP, int Pa)
 {
-  constexpr int P = 16 * NB;
   constexpr int NBLK = NB * (NB + 1) / 2;
   constexpr int E = NBLK * 4 * 64;
   __shared__ double sm[16][64];
@@ -337,9 +351,9 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict_
       }
     const int i = (ln >> 4) + 4 * reg, j = ln & 15;
     const int A = colmap<NB>(qa, i), B = colmap<NB>(qb, j);
-    if (qa != qb || i <= j) {
-      PP[A + (size_t)B * P] = tot;
-      PP[B + (size_t)A * P] = tot;
+    if ((qa != qb || i <= j) && A < Pa && B < Pa) {
+      PP[A + (size_t)B * Pa] = tot;
+      PP[B + (size_t)A * Pa] = tot;
     }
   }
 }
@@ -352,9 +366,9 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict_
 // triangle by block-row: wave w owns block-rows w and NB-1-w, i.e. exactly NB+1 blocks each, so it
 // loads two A fragments per 4-row group and one B fragment per MFMA.  Columns keep their natural
 // order here (block q = columns 16q..16q+15).
-template <int NB, int NW>
+template <int NB, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64, 2) void k_xwx_mfma_big(const double* __restrict__ tX,
-                                                             const double* __restrict__ w, int64_t N,
+                                                             const double* __restrict__ w, int64_t N, int Pa,
                                                              double* __restrict__ partial)
 {
   constexpr int P = 16 * NB;
@@ -387,7 +401,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_xwx_mfma_big(const double* __res
       const int e = t + v * NT;                                    // vector index in the tile
       const int r = e / (P / 2), cv = e % (P / 2);
       const int64_t row = tl * RT + r;
-      stage[v] = row < N ? *reinterpret_cast<const v2d*>(tX + (size_t)row * P + 2 * cv) : v2d{0.0, 0.0};
+      if (EXACT) {
+        stage[v] = row < N ? *reinterpret_cast<const v2d*>(tX + (size_t)row * P + 2 * cv) : v2d{0.0, 0.0};
+      } else {      // fewer real columns: row stride Pa, 8-byte loads, columns >= Pa are zero
+        const double* rp = tX + (size_t)(row < N ? row : 0) * (size_t)Pa;
+        const int c0 = 2 * cv, c1 = 2 * cv + 1;
+        const double v0 = rp[c0 < Pa ? c0 : Pa - 1], v1 = rp[c1 < Pa ? c1 : Pa - 1];
+        stage[v] = v2d{(row < N && c0 < Pa) ? v0 : 0.0, (row < N && c1 < Pa) ? v1 : 0.0};
+      }
     }
     if (t < RT) {
       const int64_t row = tl * RT + t;
@@ -448,9 +469,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_xwx_mfma_big(const double* __res
 // PP from the slabs of k_xwx_mfma_big (natural column order), fixed summation order.
 template <int NB>
 __global__ __launch_bounds__(1024) void k_reduce_big(const double* __restrict__ partial, int nparts,
-                                                     double* __restrict__ PP)
+                                                     double* __restrict__ PP, int Pa)
 {
-  constexpr int P = 16 * NB;
   constexpr int E = NB * (NB + 1) / 2 * 256;
   __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -474,9 +494,9 @@ __global__ __launch_bounds__(1024) void k_reduce_big(const double* __restrict__ 
     const int qb = qa + rem;
     const int i = (ln >> 4) + 4 * reg, j = ln & 15;
     const int A = 16 * qa + i, B = 16 * qb + j;
-    if (qa != qb || i <= j) {
-      PP[A + (size_t)B * P] = tot;
-      PP[B + (size_t)A * P] = tot;
+    if ((qa != qb || i <= j) && A < Pa && B < Pa) {
+      PP[A + (size_t)B * Pa] = tot;
+      PP[B + (size_t)A * Pa] = tot;
     }
   }
 }
@@ -1745,46 +1765,68 @@ inline int grid_for(int64_t n, int block, int maxb)
   return (int)g;
 }
 
-template <int NB>
+template <int NB, bool EXACT>
 void launch_draw_pass(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
                       const double* off, double* w, int64_t N, uint64_t seed, uint32_t epoch, uint64_t idx0, int mode,
                       int* status, hipStream_t s)
 {
   if (mode == blk::W_DRAW)
-    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_DRAW>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta,
-                       off, w, N, plan.chunk_rows, seed, epoch, idx0, status);
+    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_DRAW, EXACT>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n,
+                       beta, off, w, N, plan.P, plan.chunk_rows, seed, epoch, idx0, status);
   else
-    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta, off,
-                       w, N, plan.chunk_rows, seed, epoch, idx0, status);
+    hipLaunchKernelGGL((k_psi_omega_nb<NB, blk::W_EM, EXACT>), dim3(plan.nblocks_draw), dim3(kBlock), 0, s, tX, n, beta,
+                       off, w, N, plan.P, plan.chunk_rows, seed, epoch, idx0, status);
 }
 
+template <int NB, bool EXACT>
+void launch_nb_x(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
+                 double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
+                 int mode, int* status, hipStream_t s)
+{
+  constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
+  launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  hipLaunchKernelGGL((k_xwx_mfma<NB, EXACT>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, plan.P, partial);
+  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP, plan.P);
+}
 template <int NB>
 void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
                int mode, int* status, hipStream_t s)
 {
-  constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
-  launch_draw_pass<NB>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
-  hipLaunchKernelGGL((k_xwx_mfma<NB>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, partial);
-  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP);
+  if (plan.P == 16 * NB)
+    launch_nb_x<NB, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+  else
+    launch_nb_x<NB, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
 }
 
+template <int NB, int NW, bool EXACT>
+void launch_nb_big_x(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
+                     const double* off, double* w, int64_t N, double* partial, double* PP, uint64_t seed,
+                     uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+{
+  constexpr int E = NB * (NB + 1) / 2 * 256;
+  constexpr int P = 16 * NB;
+  constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
+  launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_xwx_mfma_big<NB, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_xwx_mfma_big<NB, NW, EXACT>), dim3(plan.nblocks), dim3(NW * 64), lds, s, tX, w, N, plan.P,
+                     partial);
+  hipLaunchKernelGGL((k_reduce_big<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP, plan.P);
+}
 template <int NB, int NW>
 void launch_nb_big(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
                    const double* off, double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch,
                    uint64_t idx0, int mode, int* status, hipStream_t s)
 {
-  constexpr int E = NB * (NB + 1) / 2 * 256;
-  constexpr int P = 16 * NB;
-  constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
-  launch_draw_pass<NB>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_xwx_mfma_big<NB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_xwx_mfma_big<NB, NW>), dim3(plan.nblocks), dim3(NW * 64), lds, s, tX, w, N, partial);
-  hipLaunchKernelGGL((k_reduce_big<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP);
+  if (plan.P == 16 * NB)
+    launch_nb_big_x<NB, NW, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+  else
+    launch_nb_big_x<NB, NW, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
 }
 
 }  // namespace
@@ -1814,18 +1856,18 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
 {
   SweepPlan p;
   p.P = P;
-  if (P == 128 || P == 256) {
-    p.fused = 2;                                 // LDS-tiled MFMA kernel, compute-bound
-    p.nb = P / 16;
+  if (P > 64 && P <= 256) {
+    p.fused = 2;                                 // LDS-tiled MFMA kernel (compute-bound at P = 256)
+    p.nb = P <= 128 ? 8 : 16;                    // columns padded (as zeros, in registers) to 128 / 256
     const int64_t ntiles = (N + 15) / 16;
     int64_t nb = ntiles < 1 ? 1 : ntiles;
     if (nb > (int64_t)num_cus) nb = num_cus;     // one workgroup (two waves per SIMD) per CU
     p.nblocks = (int)nb;
     plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 256;
-  } else if (P % 16 == 0 && P >= 16 && P <= 64) {
+  } else if (P >= 1 && P <= 64) {
     p.fused = 1;
-    p.nb = P / 16;
+    p.nb = (P + 15) / 16;                        // columns padded (as zeros, in registers) to 16 nb
     const int64_t ntiles = (N + 63) / 64;
     int64_t nb = (ntiles + 3) / 4;
     if (nb < 1) nb = 1;

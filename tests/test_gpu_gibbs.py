@@ -82,26 +82,47 @@ def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     g.close()
 
 
-def test_fused_and_generic_paths_agree(gpu):
-    """P = 64 (fused kernel) against the same data zero-padded to P = 65 (generic kernels)."""
+def test_kernel_paths_agree_on_padded_data(gpu):
+    """The same data with zero columns appended takes different kernels: P = 64 the register-tile MFMA
+    kernels on 16-byte loads, P = 63+1 zero... P = 65 the LDS-tile MFMA kernel with masked 8-byte loads
+    (columns padded to 128 in registers), P = 50+... any P <= 64 the register-tile kernels with masked loads,
+    P = 257 the generic kernels.  omega and the common block of X' Omega X must agree."""
     from bayeslogit_amd import device as D
-    X, y, n = synth(3000, 64, 5)
-    Xp = np.concatenate([X, np.zeros((3000, 1))], axis=1)
+    N = 3000
+    X, y, n = synth(N, 64, 5)
     beta = np.linspace(-0.2, 0.2, 64)
-    a = shard_of(X, y, n, gpu, 7)
-    b = shard_of(Xp, y, n, gpu, 7)
-    a.set_beta(beta)
-    b.set_beta(np.concatenate([beta, [0.0]]))
-    wa = torch.zeros(3000, dtype=torch.float64, device=gpu)
-    wb = torch.zeros(3000, dtype=torch.float64, device=gpu)
-    a.sweep_local(1, wa)
-    b.sweep_local(1, wb)
-    D.sync_status()
-    assert torch.allclose(wa, wb, rtol=1e-12, atol=0)
-    A = a.pp().cpu().numpy().reshape(64, 64)
-    B = b.pp().cpu().numpy().reshape(65, 65)
-    assert np.abs(A - B[:64, :64]).max() <= 1e-12 * np.abs(A).max() and np.all(B[64] == 0)
-    a.close(), b.close()
+
+    def run(Pp):
+        Xp = np.concatenate([X, np.zeros((N, Pp - 64))], axis=1) if Pp > 64 else X
+        g = shard_of(Xp, y, n, gpu, 7)
+        g.set_beta(np.concatenate([beta, np.zeros(Pp - 64)]))
+        w = torch.zeros(N, dtype=torch.float64, device=gpu)
+        g.sweep_local(1, w)
+        D.sync_status()
+        PP = g.pp().cpu().numpy().reshape(Pp, Pp).copy()
+        g.close()
+        return w, PP
+
+    wa, A = run(64)
+    for Pp in (65, 100, 128, 130, 257):
+        wb, B = run(Pp)
+        assert torch.allclose(wa, wb, rtol=1e-12, atol=0), Pp
+        assert np.abs(A - B[:64, :64]).max() <= 1e-12 * np.abs(A).max(), Pp
+        assert np.all(B[64:] == 0) and np.all(B[:, 64:] == 0), Pp
+    # fewer than 64 real columns on the register-tile path: drop columns instead of padding
+    for Pq in (63, 50, 17, 16, 15, 1):
+        Xq = np.ascontiguousarray(X[:, :Pq])
+        g = shard_of(Xq, y, n, gpu, 7)
+        g.set_beta(beta[:Pq])
+        w = torch.zeros(N, dtype=torch.float64, device=gpu)
+        g.sweep_local(1, w)
+        D.sync_status()
+        PP = g.pp().cpu().numpy().reshape(Pq, Pq)
+        wn = w.cpu().numpy()
+        ref = (Xq * wn[:, None]).T @ Xq
+        assert np.abs(PP - ref).max() <= 1e-11 * np.abs(ref).max(), Pq
+        assert np.array_equal(PP, PP.T)
+        g.close()
 
 
 def test_gibbs_dot_C_matches_oracle_short_chain(gpu, oracle):
