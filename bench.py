@@ -83,6 +83,19 @@ def timed_steps(fn, steps, warmup, world, dev):
     return wall, kern_ms
 
 
+def pmc_entry(kernel):
+    """The newest committed PMC summary's entry for `kernel` ({} if none)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(HERE, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get(kernel, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
     (profiles/rNN_pmc_summary.json: 2 x FETCH_SIZE + WRITE_SIZE, separate passes, gfx950 correction),
@@ -274,6 +287,11 @@ def main():
             "bound": "valu",
             "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
             "traffic": c2_traffic, "traffic_source": c2_traffic_src,
+            # the binding resource (same PMC summary; per launch of the default 1e8-draw workload)
+            "valu": {k: {"wave_insts_per_launch": pmc_entry(k).get("valu_insts_per_launch"),
+                         "busy_frac_of_cu_cycles": pmc_entry(k).get("valu_busy_frac"),
+                         "issue_slot_frac_lower_bound": pmc_entry(k).get("valu_issue_frac_min")}
+                     for k in ("k_rpg_devroye<1>", "k_rpg_devroye<2>")},
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": BYTES_PER_DRAW * n,
             "draws_per_s_kernel": n / (kern_ms * 1e-3),
