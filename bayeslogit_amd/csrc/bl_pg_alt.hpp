@@ -87,40 +87,61 @@ __device__ inline double alt_g_tilde(double x, double logx, double h, double tru
   return h * exp(h * kLog2 - 0.5 * log(2.0 * kPi * x * x * x) - 0.5 * h * h / x);
 }
 
-// draw_abridged(h, z, r, max_inner), PolyaGammaAlt.cpp:114-203
-__device__ inline double alt_draw_abridged(double h, double z, Stream& r, int max_inner, int& status)
+// The part of draw_abridged that depends on (h, z) only, PolyaGammaAlt.cpp:117-140: it draws nothing,
+// so a draw that calls draw_abridged several times with the same (h, z) (PolyaGammaAlt.cpp:216-222)
+// evaluates it once.
+struct AltSetup {
+  double h, z, trunc, rate_z, prob_right, coef1_h, lgam_h;
+  bool ok;
+};
+
+__device__ inline AltSetup alt_setup(double h, double z, int& status)
 {
-  if (h < 1.0 || h > 4.0) { status |= ST_BAD_SHAPE; return 0.0; }
-  z = fabs(z) * 0.5;
+  AltSetup s;
+  s.ok = !(h < 1.0 || h > 4.0);
+  if (!s.ok) {
+    status |= ST_BAD_SHAPE;
+    return s;
+  }
+  s.h = h;
+  s.z = fabs(z) * 0.5;
   const int idx = (int)floor((h - 1.0) * 100.0);
-  const double trunc = kTruncSchedule[idx];
-  const double rate_z = 0.125 * kPi * kPi + 0.5 * z * z;
-  const double lgam_h = lgamma(h);
-  const double weight_left = alt_w_left(trunc, h, z);
-  const double weight_right = alt_w_right(trunc, h, z, lgam_h);
-  const double prob_right = weight_right / (weight_right + weight_left);
-  const double coef1_h = exp(h * kLog2 - 0.5 * log(2.0 * kPi));
+  s.trunc = kTruncSchedule[idx];
+  s.rate_z = 0.125 * kPi * kPi + 0.5 * s.z * s.z;
+  s.lgam_h = lgamma(h);
+  const double weight_left = alt_w_left(s.trunc, h, s.z);
+  const double weight_right = alt_w_right(s.trunc, h, s.z, s.lgam_h);
+  s.prob_right = weight_right / (weight_right + weight_left);
+  s.coef1_h = exp(h * kLog2 - 0.5 * log(2.0 * kPi));
+  return s;
+}
+
+// draw_abridged(h, z, r, max_inner), PolyaGammaAlt.cpp:114-203: the trial loop (:142-201)
+__device__ inline double alt_draw_abridged(const AltSetup& s, Stream& r, int max_inner, int& status)
+{
+  if (!s.ok) return 0.0;
+  const double h = s.h, z = s.z, trunc = s.trunc;
   double ratio = 1.0;
 
   for (int trial = 0; trial < 10000; ++trial) {
     double X;
     const double uu = r.unif();
-    if (uu < prob_right)
-      X = ltgamma(r, h, rate_z, trunc);
+    if (uu < s.prob_right)
+      X = ltgamma(r, h, s.rate_z, trunc);
     else
       X = alt_rtigauss(h, z, trunc, r, status);
     const double logx = log(X);
     const double lx3 = log(X * X * X);
-    double S = alt_a_coef_rec(0.0, X, lx3, h, coef1_h, ratio);
+    double S = alt_a_coef_rec(0.0, X, lx3, h, s.coef1_h, ratio);
     double a_n = S;
-    const double gt = alt_g_tilde(X, logx, h, trunc, lgam_h);
+    const double gt = alt_g_tilde(X, logx, h, trunc, s.lgam_h);
     const double Y = r.unif() * gt;
     int n = 0;
     bool go = true;
     while (go && n < max_inner) {
       ++n;
       const double prev = a_n;
-      a_n = alt_a_coef_rec((double)n, X, lx3, h, coef1_h, ratio);
+      a_n = alt_a_coef_rec((double)n, X, lx3, h, s.coef1_h, ratio);
       const bool decreasing = a_n <= prev;
       if (n & 1) {
         S = S - a_n;
@@ -142,13 +163,18 @@ __device__ inline double alt_draw(double h, double z, Stream& r, int& status)
   const double n = floor((h - 1.0) / 4.0);
   const double remain = h - 4.0 * n;
   double x = 0.0;
-  for (int i = 0; i < (int)n; i++) x += alt_draw_abridged(4.0, z, r, 200, status);
+  if ((int)n > 0) {
+    const AltSetup s4 = alt_setup(4.0, z, status);
+    for (int i = 0; i < (int)n; i++) x += alt_draw_abridged(s4, r, 200, status);
+  }
   if (remain > 4.0) {
-    const double a = alt_draw_abridged(0.5 * remain, z, r, 200, status);
-    const double b = alt_draw_abridged(0.5 * remain, z, r, 200, status);
+    const AltSetup sh = alt_setup(0.5 * remain, z, status);
+    const double a = alt_draw_abridged(sh, r, 200, status);
+    const double b = alt_draw_abridged(sh, r, 200, status);
     x += a + b;
   } else {
-    x += alt_draw_abridged(remain, z, r, 200, status);
+    const AltSetup sr = alt_setup(remain, z, status);
+    x += alt_draw_abridged(sr, r, 200, status);
   }
   return x;
 }
