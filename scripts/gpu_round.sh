@@ -19,7 +19,7 @@ step() {  # name, timeout, command...
 step pytest_gpu 600 python -m pytest tests -m gpu -q
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
 step bench 500 python bench.py --mixed --c5
-BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu"
+BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu --mixed"
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_*_$TAG
 step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py $BARGS
 find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" gpurun_out/kernel_stats_$TAG.csv; done
