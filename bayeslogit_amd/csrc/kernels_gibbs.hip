@@ -1467,8 +1467,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // Speculation.  A move's value is almost always the Box-Muller normal of its first attempt (the bounds
   // contain 0, are wider than sqrt(2 pi), and the normal falls inside: tnorm_lanes' first branch, attempt
   // 0).  That normal is known before the bounds are: the move is applied with it at once -- beta, z
-  // updated, the next move started -- and its bounds (the 64-lane max/min, the long part of a move) are
-  // reduced and checked one move later, off the dependent chain.  A failed check rolls the two moves
+  // updated, the next move started -- and its bounds are checked one move later, off the dependent chain:
+  // first by a ballot on a sufficient condition, and only if that fails by the 64-lane max/min (the
+  // long part of a move).  A failed check rolls the two moves
   // in flight back (beta before the checked move is kept; z by the two saved scalars), redoes the checked
   // move through tnorm_lanes and restarts the next one; results are those of the move-by-move loop.
   const int lane = t & 63;
@@ -1506,10 +1507,28 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // checks the move in flight; on failure undoes it (and, if undo_next, the later move applied on top of
   // it, whose z was z1_next at coordinate c_next) and redoes it exactly.  Returns false if it was redone.
   auto check = [&](bool undo_next, int c_next, double z1_next) -> bool {
+    // sufficient tests without the reduction: every lower candidate <= min(s, -a) and every upper
+    // candidate >= max(s, b) with a, b >= 0, a + b > sqrt(2 pi) = 2.5066... imply lo <= 0 <= hi,
+    // hi - lo > sqrt(2 pi) and lo <= s <= hi; tried for (a, b) = (1.26, 1.26), (0, 2.51), (2.51, 0)
+    // (one-sided bounds -- the usual case -- pass the second or third whatever the finite side is)
+    {
+      const double s = s_p;
+      const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
+      const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
+      const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
+      if (__ballot(lo_p > l1s || hi_p < h1s) == 0ull || __ballot(lo_p > l0 || hi_p < h2s) == 0ull ||
+          __ballot(lo_p > l2s || hi_p < h0) == 0ull) {
+        if (a.dbg && lane == 0) a.dbg[1] += 1;          // development aid: moves confirmed by a ballot
+        return true;
+      }
+    }
     double lo = lo_p, hi = hi_p;
     wave_maxmin(lo, hi);
     const bool ok = lo <= 0.0 && hi >= 0.0 && hi - lo > 2.5066282746310002 && s_p >= lo && s_p <= hi;
-    if (ok) return true;
+    if (ok) {
+      if (a.dbg && lane == 0) a.dbg[2] += 1;            // ... confirmed by the reduction
+      return true;
+    }
     if (undo_next && lane == c_next) zj = z1_next;
     if (lane == c_p) zj = z1_p;
     bj = bj_p;
