@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--gibbs-p", type=int, default=64)
     ap.add_argument("--gibbs-sweeps", type=int, default=30)
     ap.add_argument("--no-gibbs", action="store_true")
+    ap.add_argument("--gibbs-chain", type=int, default=1000,
+                    help="C4 only: also run a chain of 100 burn-in + this many sampling sweeps (SURVEY 8d: posterior "
+                         "mean and sd of beta, sweeps/s over the sampling phase); 0 = skip")
     ap.add_argument("--c5", action="store_true", help="also time one GPU's shard of config C5 (12.5e6 x 256 per rank)")
     ap.add_argument("--c5-sweeps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -130,7 +133,7 @@ def cpu_baseline(draws_sample, ncores):
     return one, allc
 
 
-def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range):
+def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, chain=0):
     """Gibbs sweeps/s on an N x P problem with rows sharded over the ranks: per sweep one pass over this
     rank's rows (psi, omega, X' Omega X), one P*P all-reduce, the replicated P x P stage."""
     lo, hi = shard_range(N, rank, world)
@@ -180,6 +183,34 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range):
         res[name] = {"sweeps_per_s": sweeps / gw, "ms_per_sweep": gw / sweeps * 1e3,
                      "sweep_kernel_ms": sweep_ms, "allreduce_plus_beta_ms": beta_ms}
     D.sync_status()
+    chain_out = None
+    if chain > 0:
+        # the reference's run shape (Logit.hpp:460-481): beta = 0, 100 burn-in sweeps, `chain` sampling sweeps with
+        # the fork's active (constrained) draw; omega is not stored; moments of beta accumulated on the device
+        burn = 100
+        shard.set_beta(np.zeros(P))
+        bsum = torch.zeros(P, dtype=torch.float64, device=dev)
+        bsq = torch.zeros(P, dtype=torch.float64, device=dev)
+        for s_ in range(burn):
+            drv.sweep(s_, 1)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for s_ in range(burn, burn + chain):
+            drv.sweep(s_, 1)
+            b = shard.beta()
+            bsum += b
+            bsq += b * b
+        barrier_sync(world)
+        cw = max_over_ranks(time.perf_counter() - t0, world, dev)
+        D.sync_status()
+        mean = (bsum / chain).cpu().numpy()
+        sd = np.sqrt(np.maximum((bsq / chain).cpu().numpy() - mean * mean, 0.0) * chain / max(chain - 1, 1))
+        bt_h = bt.cpu().numpy()
+        chain_out = {"burn": burn, "samp": chain, "sweeps_per_s_sampling_phase": chain / cw,
+                     "beta_post_mean_head": [float(v) for v in mean[:4]], "beta_post_sd_head": [float(v) for v in sd[:4]],
+                     "beta_post_mean_intercept": float(mean[-1]), "beta_true_head": [float(v) for v in bt_h[:4]],
+                     "beta_true_intercept": float(bt_h[-1]),
+                     "max_abs_z": float(np.max(np.abs(mean - bt_h) / np.maximum(sd, 1e-300)))}
     sk = res["constrained"]["sweep_kernel_ms"]
     gb = 8.0 * nl * P / (sk * 1e-3) / 1e9
     if P <= 64:
@@ -189,8 +220,9 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range):
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": 8 * nl * P,
                 "note": "algorithmic bytes = X once (SURVEY 8d); the sweep reads X twice (DESIGN.md 4.3)"}
-        t1, src = pmc_traffic(f"k_psi_omega_nb<{nbk}, 0>")
-        t2, _ = pmc_traffic(f"k_xwx_mfma<{nbk}>")
+        exact = "true" if P == 16 * nbk else "false"
+        t1, src = pmc_traffic(f"k_psi_omega_nb<{nbk}, 0, {exact}>")
+        t2, _ = pmc_traffic(f"k_xwx_mfma<{nbk}, {exact}>")
         roof["traffic"] = (t1 + t2) if (t1 and t2 and N == 10_000_000 and world == 1) else None
         roof["traffic_source"] = src
     else:
@@ -213,7 +245,7 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range):
                      "unconstrained = Logit.hpp:291-320",
         **res,
         "roofline": roof,
-        "beta_mean_head": [float(v) for v in shard.get_beta()[:4]],
+        "chain": chain_out,
     }
     shard.close()
     del X, y, nn
@@ -314,7 +346,7 @@ def main():
     # ---------------------------------------------------------------- C4: Gibbs sweeps
     if not a.no_gibbs:
         out["gibbs"] = gibbs_bench(a.gibbs_n, a.gibbs_p, a.gibbs_sweeps, "C4", rank, world, dev, D, DistGibbs,
-                                   shard_range)
+                                   shard_range, chain=a.gibbs_chain)
     # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
     if a.c5:
         out["gibbs_c5"] = gibbs_bench(12_500_000 * world, 256, a.c5_sweeps, "C5 shard", rank, world, dev, D,

@@ -19,11 +19,11 @@ step() {  # name, timeout, command...
 step pytest_gpu 600 python -m pytest tests -m gpu -q
 step smoke 200 python -c "import __graft_entry__ as g; g.smoke()"
 step bench 500 python bench.py --mixed --c5
-BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --no-cpu --mixed"
+BARGS="--steps 5 --warmup 1 --gibbs-sweeps 10 --gibbs-chain 0 --no-cpu --mixed"
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_*_$TAG
 step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -- python3 bench.py $BARGS
 find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" gpurun_out/kernel_stats_$TAG.csv; done
-PARGS="--steps 2 --warmup 1 --gibbs-sweeps 3 --no-cpu"
+PARGS="--steps 2 --warmup 1 --gibbs-sweeps 3 --gibbs-chain 0 --no-cpu"
 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py $PARGS
 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py $PARGS
 step pmc_valu 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu_$TAG -- python3 bench.py $PARGS
