@@ -214,24 +214,27 @@ BL_HD bool pg1_attempt(Pg1Lane& s, const Pg1Par& p, double u1, double u2, int& s
     const double X = kSmT + (FAST ? bl_div(E, p.fz) : E / p.fz);
     return pg1_decide<FAST>(s, X, 1.0, -kSmPiSq * X, u2, status);
   }
-  // mu <= t: inverse-Gaussian candidate from one normal, PolyaGamma.cpp:103-113
-  const double mu = 1.0 / p.Z;
+  // mu <= t: inverse-Gaussian candidate from one normal, PolyaGamma.cpp:103-113 (divides and the square
+  // root in bl_fastmath's short forms when FAST: <= 1 ulp from the IEEE sequences)
+  const double mu = FAST ? bl_div(1.0, p.Z) : 1.0 / p.Z;
   double Y = qnorm(w);
   Y *= Y;
   const double half_mu = 0.5 * mu;
   const double mu_Y = mu * Y;
-  const double X0 = mu + half_mu * mu_Y - half_mu * sqrt(4.0 * mu_Y + mu_Y * mu_Y);
-  const double pk = mu / (mu + X0);
+  const double rad = 4.0 * mu_Y + mu_Y * mu_Y;
+  const double X0 = mu + half_mu * mu_Y - half_mu * ((FAST && rad > 1e-300 && rad < 1e300) ? bl_sqrt(rad) : sqrt(rad));
+  const double pk = FAST ? bl_div(mu, mu + X0) : mu / (mu + X0);
   const bool flip = u2 > pk;                                                     // :110
-  const double X = flip ? mu * mu / X0 : X0;
+  const double X = flip ? (FAST ? bl_div(mu * mu, X0) : mu * mu / X0) : X0;
   if (X > kSmT) {                                                                // :105
     s.fresh = false;
     return false;
   }
-  double v = flip ? (u2 - pk) / (1.0 - pk) : u2 / pk;                            // the rest of u2
+  const double vn = flip ? u2 - pk : u2, vd = flip ? 1.0 - pk : pk;              // the rest of u2
+  double v = FAST ? bl_div(vn, vd) : vn / vd;
   v = v < kSmWMin ? kSmWMin : v;
   v = v > kSmWMax ? kSmWMax : v;
-  return pg1_decide<FAST>(s, X, 1.0, -4.0 / X, v, status);
+  return pg1_decide<FAST>(s, X, 1.0, FAST ? bl_div(-4.0, X) : -4.0 / X, v, status);
 }
 
 // Sum of n PG(1, z) draws (PolyaGamma::draw(int n, z, r), :126-140; n < 1 -> 1 in the NTHROW
