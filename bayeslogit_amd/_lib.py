@@ -30,6 +30,8 @@ SIGNATURES = {
     "bl_set_seed_from_unif": (None, [c_dp]),
     "bl_get_epoch": (c_u32, []),
     "bl_set_constrain": (None, [C.c_int]),
+    "bl_set_constrain_R": (None, [c_ip]),
+    "bl_set_device_R": (None, [c_ip, c_ip]),
     "rpg_gamma": (None, [c_dp, c_dp, c_dp, c_ip, c_ip]),
     "rpg_devroye": (None, [c_dp, c_ip, c_dp, c_ip]),
     "rpg_alt": (None, [c_dp, c_dp, c_dp, c_ip]),

@@ -133,6 +133,12 @@ void bl_set_seed_from_unif(double* u)
 }
 uint32_t bl_get_epoch(void) { return g_epoch.load(); }
 void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
+void bl_set_constrain_R(int* c) { g_constrain = (c && *c) ? 1 : 0; }
+void bl_set_device_R(int* device, int* rc)
+{
+  const int r = bl_set_device(device ? *device : 0);
+  if (rc) *rc = r;
+}
 
 int bl_sync_status(void* stream)
 {

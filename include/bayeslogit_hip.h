@@ -59,6 +59,9 @@ uint32_t bl_get_epoch(void);
  * draw (Logit.hpp:322-400, call site :429), 0 = unconstrained MVN (Logit.hpp:291-320).
  * Default 1, i.e. what the reference's gibbs() actually executes. */
 void     bl_set_constrain(int constrain);
+/* the same two knobs with R's .C calling convention (every argument a pointer) */
+void     bl_set_constrain_R(int *constrain);
+void     bl_set_device_R(int *device, int *rc);
 
 /* LogitWrapper.h:27 */ void rpg_gamma  (double *x, double *n, double *z, int *num, int *trunc);
 /* LogitWrapper.h:29 */ void rpg_devroye(double *x, int *n, double *z, int *num);

@@ -16,4 +16,4 @@
 ## mlogit (LogitWrapper.R:323-368): the same line before .C("mult_gibbs", ...)
 
 ## optional: the unconstrained beta draw that Logit.hpp:430 comments out
-    .C("bl_set_constrain", as.integer(0), PACKAGE="BayesLogit")
+    .C("bl_set_constrain_R", as.integer(0), PACKAGE="BayesLogit")
