@@ -191,9 +191,6 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
     fprintf(stderr, "beta stage (us): chol %.1f inverse %.1f rest of dense (wave 0; waves 1-3 generate randoms) %.1f scan tables %.1f serial %.1f\n",
             (st[3] - st[0]) / 100.0, st[4] ? (st[4] - st[3]) / 100.0 : 0.0, (st[5] - (st[4] ? st[4] : st[3])) / 100.0,
             st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
-    if (constrain && h->P <= 64)
-      fprintf(stderr, "  speculative moves: %llu confirmed by ballot, %llu by reduction, %llu redone (of %d)\n", st[1], st[2],
-              (unsigned long long)h->P * h->P - st[1] - st[2], h->P * h->P);
   }
   return BL_OK;
 }

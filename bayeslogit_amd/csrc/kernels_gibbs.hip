@@ -1517,18 +1517,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
       const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
       if (__ballot(lo_p > l1s || hi_p < h1s) == 0ull || __ballot(lo_p > l0 || hi_p < h2s) == 0ull ||
-          __ballot(lo_p > l2s || hi_p < h0) == 0ull) {
-        if (a.dbg && lane == 0) a.dbg[1] += 1;          // development aid: moves confirmed by a ballot
+          __ballot(lo_p > l2s || hi_p < h0) == 0ull)
         return true;
-      }
     }
     double lo = lo_p, hi = hi_p;
     wave_maxmin(lo, hi);
     const bool ok = lo <= 0.0 && hi >= 0.0 && hi - lo > 2.5066282746310002 && s_p >= lo && s_p <= hi;
-    if (ok) {
-      if (a.dbg && lane == 0) a.dbg[2] += 1;            // ... confirmed by the reduction
-      return true;
-    }
+    if (ok) return true;
     if (undo_next && lane == c_next) zj = z1_next;
     if (lane == c_p) zj = z1_p;
     bj = bj_p;

@@ -5,7 +5,7 @@ import numpy as np, torch
 from bayeslogit_amd import device as D
 from bayeslogit_amd.dist import DistGibbs
 dev = torch.device("cuda:0")
-N, P = 10_000_000, 64
+N, P = int(os.environ.get("BL_N", "10000000")), 64
 X = torch.empty((N, P), dtype=torch.float64, device=dev); D.fill_norm(X, 0.0, 1 / 8.0, 20240003); X[:, -1] = 1.0
 bt = torch.empty(P, dtype=torch.float64, device=dev); D.fill_norm(bt, 0.0, 1.0, 20240003, epoch=1); bt.abs_(); bt[-1] = -0.5
 y = torch.empty(N, dtype=torch.float64, device=dev); D.fill_logit_y(y, X, bt, 20240003, epoch=2)
