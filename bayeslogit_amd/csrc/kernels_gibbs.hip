@@ -1464,14 +1464,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // The serial coordinate sweeps run on wave 0; waves 1-3 stage the next scan's random records
   // from global scratch into LDS meanwhile (one barrier per scan), so a move reads only LDS.
   //
-  // Speculation.  A move's value is almost always the Box-Muller normal of its first attempt (the bounds
-  // contain 0, are wider than sqrt(2 pi), and the normal falls inside: tnorm_lanes' first branch, attempt
-  // 0).  That normal is known before the bounds are: the move is applied with it at once -- beta, z
-  // updated, the next move started -- and its bounds are checked one move later, off the dependent chain:
-  // first by a ballot on a sufficient condition, and only if that fails by the 64-lane max/min (the
-  // long part of a move).  A failed check rolls the two moves
-  // in flight back (beta before the checked move is kept; z by the two saved scalars), redoes the checked
-  // move through tnorm_lanes and restarts the next one; results are those of the move-by-move loop.
+  // Fast path.  A move's value is almost always the Box-Muller normal s of its first attempt: the bounds
+  // contain 0, are wider than sqrt(2 pi), and s falls inside (tnorm_lanes' first branch, attempt 0).  That
+  // is decided WITHOUT reducing the bounds: if every lane's lower candidate is <= min(s, -a) and every upper
+  // candidate >= max(s, b) for some a, b >= 0 with a + b > sqrt(2 pi), then lo <= 0 <= hi, hi - lo > sqrt(2 pi)
+  // and lo <= s <= hi -- three __ballot tests ((a, b) = (1.26, 1.26), (0, 2.51), (2.51, 0): one-sided bounds,
+  // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
+  // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
   const int lane = t & 63;
   const bool serial = t < 64;
   const bool row = serial && lane < P;
@@ -1481,58 +1480,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   const int nrec = P * kRec;
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
-  // the move in flight (applied, bounds not yet checked)
-  bool pend = false;
-  int c_p = 0;
-  double lo_p = -inf, hi_p = inf, s_p = 0.0, z1_p = 0.0, l1_p = 0.0, bj_p = 0.0;
-  double r0_p = 0.0, r1_p = 0.0, r2_p = 0.0, r3_p = 0.0;
-  // applies move (c, l1, ri, record) speculatively on the current (bj, zj) and makes it the move in flight
-  auto speculate = [&](int c, double l1, double ri, double r0, double r1, double r2, double r3) {
-    const double z1 = readlane_f64(zj, c);
-    const double c1 = z1 - bj * ri;
-    const bool in = row && lane >= c && lane < P - 1;
-    lo_p = (in && l1 > 0.0) ? c1 : -inf;
-    hi_p = (in && l1 < 0.0) ? c1 : inf;
-    s_p = readlane_f64(r3, 0);                     // attempt 0's normal
-    z1_p = z1;
-    c_p = c;
-    l1_p = l1;
-    r0_p = r0; r1_p = r1; r2_p = r2; r3_p = r3;
-    bj_p = bj;
-    const double dz = s_p - z1;
-    if (row && lane >= c) bj += l1 * dz;
-    if (lane == c) zj = s_p;
-    pend = true;
-  };
-  // checks the move in flight; on failure undoes it (and, if undo_next, the later move applied on top of
-  // it, whose z was z1_next at coordinate c_next) and redoes it exactly.  Returns false if it was redone.
-  auto check = [&](bool undo_next, int c_next, double z1_next) -> bool {
-    // sufficient tests without the reduction: every lower candidate <= min(s, -a) and every upper
-    // candidate >= max(s, b) with a, b >= 0, a + b > sqrt(2 pi) = 2.5066... imply lo <= 0 <= hi,
-    // hi - lo > sqrt(2 pi) and lo <= s <= hi; tried for (a, b) = (1.26, 1.26), (0, 2.51), (2.51, 0)
-    // (one-sided bounds -- the usual case -- pass the second or third whatever the finite side is)
-    {
-      const double s = s_p;
-      const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
-      const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
-      const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
-      if (__ballot(lo_p > l1s || hi_p < h1s) == 0ull || __ballot(lo_p > l0 || hi_p < h2s) == 0ull ||
-          __ballot(lo_p > l2s || hi_p < h0) == 0ull)
-        return true;
-    }
-    double lo = lo_p, hi = hi_p;
-    wave_maxmin(lo, hi);
-    const bool ok = lo <= 0.0 && hi >= 0.0 && hi - lo > 2.5066282746310002 && s_p >= lo && s_p <= hi;
-    if (ok) return true;
-    if (undo_next && lane == c_next) zj = z1_next;
-    if (lane == c_p) zj = z1_p;
-    bj = bj_p;
-    const double z2 = tnorm_lanes(r0_p, r1_p, r2_p, r3_p, lane, lo, hi);
-    const double dz = z2 - z1_p;
-    if (row && lane >= c_p) bj += l1_p * dz;
-    if (lane == c_p) zj = z2;
-    return false;
-  };
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
     if (!serial) {
@@ -1563,34 +1510,28 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           q2 = Rn[2];
           q3 = Rn[3];
         }
-        if (!pend) {
-          speculate(c, l1, ri, r0, r1, r2, r3);
-          continue;
+        const double z1 = readlane_f64(zj, c);
+        const double c1 = z1 - bj * ri;
+        const bool in = row && lane >= c && lane < P - 1;
+        double lo = (in && l1 > 0.0) ? c1 : -inf;
+        double hi = (in && l1 < 0.0) ? c1 : inf;
+        const double s = readlane_f64(r3, 0);                        // attempt 0's normal
+        const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
+        const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
+        const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
+        double z2 = s;
+        if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
+              __ballot(lo > l2s || hi < h0) == 0ull)) {
+          wave_maxmin(lo, hi);
+          z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
         }
-        // the previous move is in flight: keep what its check needs, apply this move on top of it
-        const int c_q = c_p;
-        const double lo_q = lo_p, hi_q = hi_p, s_q = s_p, z1_q = z1_p, l1_q = l1_p, bj_q = bj_p;
-        const double r0_q = r0_p, r1_q = r1_p, r2_q = r2_p, r3_q = r3_p;
-        speculate(c, l1, ri, r0, r1, r2, r3);                         // overwrites the *_p set
-        // check the previous move (independent of the lines above until the branch)
-        const int c_cur = c_p;
-        const double z1_cur = z1_p;
-        const double lo_c = lo_p, hi_c = hi_p, s_c = s_p, l1_c = l1_p, bj_c = bj_p;
-        c_p = c_q; lo_p = lo_q; hi_p = hi_q; s_p = s_q; z1_p = z1_q; l1_p = l1_q; bj_p = bj_q;
-        r0_p = r0_q; r1_p = r1_q; r2_p = r2_q; r3_p = r3_q;
-        if (check(true, c_cur, z1_cur)) {
-          // previous move confirmed: this move stays in flight
-          c_p = c_cur; lo_p = lo_c; hi_p = hi_c; s_p = s_c; z1_p = z1_cur; l1_p = l1_c; bj_p = bj_c;
-          r0_p = r0; r1_p = r1; r2_p = r2; r3_p = r3;
-        } else {
-          // previous move redone from its own state: this move is applied again on the corrected state
-          speculate(c, l1, ri, r0, r1, r2, r3);
-        }
+        const double dz = z2 - z1;
+        bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
+        zj = lane == c ? z2 : zj;
       }
     }
     __syncthreads();
   }
-  if (serial && pend) (void)check(false, 0, 0.0);
   if (row) a.beta_out[lane] = bj;
   if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
 }
