@@ -1635,13 +1635,6 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
   }
   for (int e = t; e < nrec; e += nthr) recL[e] = rec[e];
   __syncthreads();
-  // the move in flight (applied, bounds not yet checked)
-  bool pend = false;
-  int c_p = 0;
-  double s_p = 0.0, z1_p = 0.0, lo_p = -inf, hi_p = inf, r0_p = 0.0, r1_p = 0.0, r2_p = 0.0, r3_p = 0.0;
-  double l1_p[RPL], bj_p[RPL];
-#pragma unroll
-  for (int r = 0; r < RPL; ++r) l1_p[r] = bj_p[r] = 0.0;
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
     if (!serial) {
@@ -1705,86 +1698,34 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
               q2 = Rn[2];
               q3 = Rn[3];
             }
-            // speculative move (see k_beta64): applied with attempt 0's normal; checked one move later
-            const double s_c = readlane_f64(r3, 0);
-            double z1_c = z1_n;
-            double lo_c = -inf, hi_c = inf, bj_c[RPL];
-            auto apply_cur = [&]() {
-              lo_c = -inf;
-              hi_c = inf;
-#pragma unroll
-              for (int r = 0; r < RPL; ++r) {
-                lo_c = vmax64(lo_c, z1_c - bj[r] * rl[r]);      // NaN (row not in the lower set) leaves lo as it is
-                hi_c = vmin64(hi_c, z1_c - bj[r] * rh[r]);
-                bj_c[r] = bj[r];
-              }
-              const double dz = s_c - z1_c;
-#pragma unroll
-              for (int r = 0; r < RPL; ++r) bj[r] += l1[r] * dz;    // L(j, c) = 0 for j < c: rows above c do not move
-              if (lane == 0) sz[c] = s_c;
-            };
-            apply_cur();
-            if (pend) {
-              const double sp = s_p;
-              const double l1s = sp < -1.26 ? sp : -1.26, h1s = sp > 1.26 ? sp : 1.26;
-              const double l0s = sp < 0.0 ? sp : 0.0, h0s = sp > 0.0 ? sp : 0.0;
-              const double l2s = sp < -2.51 ? sp : -2.51, h2s = sp > 2.51 ? sp : 2.51;
-              const bool fast = __ballot(lo_p > l1s || hi_p < h1s) == 0ull || __ballot(lo_p > l0s || hi_p < h2s) == 0ull ||
-                                __ballot(lo_p > l2s || hi_p < h0s) == 0ull;
-              if (!fast) {
-                double lo = lo_p, hi = hi_p;
-                wave_maxmin(lo, hi);
-                const bool ok = lo <= 0.0 && hi >= 0.0 && hi - lo > 2.5066282746310002 && sp >= lo && sp <= hi;
-                if (!ok) {
-                  // undo this move and the checked one, redo the checked one exactly, apply this one again
-                  if (lane == 0) {
-                    sz[c] = z1_c;
-                    sz[c_p] = z1_p;
-                  }
-#pragma unroll
-                  for (int r = 0; r < RPL; ++r) bj[r] = bj_p[r];
-                  const double z2 = tnorm_lanes(r0_p, r1_p, r2_p, r3_p, lane, lo, hi);
-                  const double dz = z2 - z1_p;
-#pragma unroll
-                  for (int r = 0; r < RPL; ++r) bj[r] += l1_p[r] * dz;
-                  if (lane == 0) sz[c_p] = z2;
-                  z1_c = sz[c];
-                  apply_cur();
-                }
-              }
-            }
-            // this move is now the one in flight
-            pend = true;
-            c_p = c;
-            s_p = s_c;
-            z1_p = z1_c;
-            lo_p = lo_c;
-            hi_p = hi_c;
-            r0_p = r0; r1_p = r1; r2_p = r2; r3_p = r3;
+            // fast path of k_beta64: attempt 0's normal is the move's value if three ballots say so
+            const double z1 = z1_n;
+            double lo = -inf, hi = inf;
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-              l1_p[r] = l1[r];
-              bj_p[r] = bj_c[r];
+              lo = vmax64(lo, z1 - bj[r] * rl[r]);      // NaN (row not in the lower set) leaves lo as it is
+              hi = vmin64(hi, z1 - bj[r] * rh[r]);
             }
+            const double s0 = readlane_f64(r3, 0);
+            const double l0s = s0 < 0.0 ? s0 : 0.0, h0s = s0 > 0.0 ? s0 : 0.0;
+            const double l1s = s0 < -1.26 ? s0 : -1.26, h1s = s0 > 1.26 ? s0 : 1.26;
+            const double l2s = s0 < -2.51 ? s0 : -2.51, h2s = s0 > 2.51 ? s0 : 2.51;
+            double z2 = s0;
+            if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0s || hi < h2s) == 0ull ||
+                  __ballot(lo > l2s || hi < h0s) == 0ull)) {
+              wave_maxmin(lo, hi);
+              z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+            }
+            const double dz = z2 - z1;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) bj[r] += l1[r] * dz;    // L(j, c) = 0 for j < c: rows above c do not move
+            if (lane == 0) sz[c] = z2;
             if (i + 1 < P) z1_n = sz[__builtin_amdgcn_readfirstlane(c_n)];   // after the stores above in program order
           }
         }
       }
     }
     __syncthreads();
-  }
-  if (serial && pend) {      // the last move is still in flight
-    double lo = lo_p, hi = hi_p;
-    wave_maxmin(lo, hi);
-    const bool ok = lo <= 0.0 && hi >= 0.0 && hi - lo > 2.5066282746310002 && s_p >= lo && s_p <= hi;
-    if (!ok) {
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) bj[r] = bj_p[r];
-      const double z2 = tnorm_lanes(r0_p, r1_p, r2_p, r3_p, lane, lo, hi);
-      const double dz = z2 - z1_p;
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) bj[r] += l1_p[r] * dz;
-    }
   }
   if (serial) {
 #pragma unroll
