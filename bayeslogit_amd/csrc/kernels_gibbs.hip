@@ -1390,8 +1390,15 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         m = w_solve_U_vec(A, m, P, ld, lane);                                 // mP
         ok = w_chol_lower(S, P, ld, lane);                                    // L = chol(S,'L')
         if (ok) {
+          // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0,
+          // A (U is dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the ballots ignore NaN
           for (int j = 0; j < P; ++j)
-            if (lane < P) L_(Ri, lane, j) = 1.0 / L_(S, lane, j);
+            if (lane < P) {
+              const double l = L_(S, lane, j), r = 1.0 / l;
+              const double nan = __builtin_nan("");
+              L_(Ri, lane, j) = (l > 0.0 && lane < P - 1) ? r : nan;
+              L_(A, lane, j) = (l < 0.0 && lane < P - 1) ? r : nan;
+            }
           double z = lane < P ? a.beta_prev[lane] - m : 0.0;                 // z = L^{-1}(beta_prev - mP)
           z = w_solve_L_vec(S, z, P, ld, lane);
           if (lane < P) zz[lane] = z;
@@ -1493,17 +1500,20 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       const int g4 = (lane < 5 ? lane : 0) * 4;
       int c_n = __builtin_amdgcn_readfirstlane(ptab[k * P]);
       int c_nn = ptab[k * P + (P > 1 ? 1 : 0)];                    // two moves ahead (still a VGPR)
-      double l1_n = row ? L_(S, lane, c_n) : 0.0, ri_n = row ? L_(Ri, lane, c_n) : 0.0;
+      const double qnan = __builtin_nan("");
+      const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
+      double l1_n = row ? L_(S, lr, c_n) : 0.0, rl_n = row ? L_(Ri, lr, c_n) : qnan, rh_n = row ? L_(A, lr, c_n) : qnan;
       double q0 = Rk[g4], q1 = Rk[g4 + 1], q2 = Rk[g4 + 2], q3 = Rk[g4 + 3];
       for (int i = 0; i < P; ++i) {
         const int c = c_n;
-        const double l1 = l1_n, ri = ri_n;
+        const double l1 = l1_n, rl = rl_n, rh = rh_n;
         const double r0 = q0, r1 = q1, r2 = q2, r3 = q3;
         if (i + 1 < P) {
           c_n = __builtin_amdgcn_readfirstlane(c_nn);
           c_nn = ptab[k * P + (i + 2 < P ? i + 2 : i + 1)];
-          l1_n = row ? L_(S, lane, c_n) : 0.0;
-          ri_n = row ? L_(Ri, lane, c_n) : 0.0;
+          l1_n = row ? L_(S, lr, c_n) : 0.0;
+          rl_n = row ? L_(Ri, lr, c_n) : qnan;
+          rh_n = row ? L_(A, lr, c_n) : qnan;
           const double* Rn = Rk + (i + 1) * kRec + g4;
           q0 = Rn[0];
           q1 = Rn[1];
@@ -1511,10 +1521,8 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           q3 = Rn[3];
         }
         const double z1 = readlane_f64(zj, c);
-        const double c1 = z1 - bj * ri;
-        const bool in = row && lane >= c && lane < P - 1;
-        double lo = (in && l1 > 0.0) ? c1 : -inf;
-        double hi = (in && l1 < 0.0) ? c1 : inf;
+        double lo = z1 - bj * rl;                                    // NaN: this row does not bound the move from below
+        double hi = z1 - bj * rh;
         const double s = readlane_f64(r3, 0);                        // attempt 0's normal
         const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
         const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
@@ -1522,7 +1530,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         double z2 = s;
         if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
               __ballot(lo > l2s || hi < h0) == 0ull)) {
-          wave_maxmin(lo, hi);
+          wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
+          lo = lo == lo ? lo : -inf;
+          hi = hi == hi ? hi : inf;
           z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
         }
         const double dz = z2 - z1;
