@@ -1243,6 +1243,56 @@ __device__ bool w_chol_lower(double* S, int P, int ld, int lane)
   return true;
 }
 
+// Register-resident Cholesky on one wavefront (P <= 64): lane i keeps row i of the (upper) triangle in 64
+// registers, so a step touches LDS only to pass the pivot row around (one 64-double buffer), not to update
+// the trailing matrix.  Same arithmetic as w_chol_upper / w_chol_lower -- u_kj = a_kj / sqrt(a_kk), then
+// a_ij -= u_ki u_kj, k ascending (a product of the same two numbers either way round) -- so the factor is
+// bit-identical; LOWER = false: A = U'U, reads and writes the upper triangle of M; LOWER = true: M = L L', reads
+// the lower triangle of M (row i of the transposed problem is column i of the lower triangle), writes L = U'
+// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS.  Measured in k_beta64: the upper form
+// 65 us against w_chol_upper's 130; the lower form is SLOWER than w_chol_lower (whose row-per-lane LDS accesses
+// are already conflict-free), so only <false> is used.
+template <bool LOWER>
+__device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
+{
+  double r[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const bool in = lane < P && j < P && j >= lane;
+    r[j] = in ? (LOWER ? L_(M, j, lane) : L_(M, lane, j)) : 0.0;
+  }
+  for (int k = 0; k < P; ++k) {
+    if (lane == k) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) buf[j] = r[j];
+    }
+    WAVE_SYNC();
+    const double akk = buf[k];
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    const double a_kl = buf[lane];
+    WAVE_SYNC();
+    double u = 0.0;
+    if (lane > k && lane < P) u = a_kl / d;
+    if (lane >= k && lane < P) {
+      const double v = lane == k ? d : u;
+      if (LOWER) L_(M, lane, k) = v;
+      else L_(M, k, lane) = v;
+    }
+    buf[lane] = u;                                 // u_kj for j > k, 0 for j <= k and outside the matrix
+    WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < 64; ++j) r[j] = fma(-u, buf[j], r[j]);     // rows i <= k have u = 0: unchanged
+    WAVE_SYNC();
+  }
+  if (LOWER) {
+    for (int j = 1; j < P; ++j)
+      if (lane < j && lane < P) L_(M, lane, j) = 0.0;
+    WAVE_SYNC();
+  }
+  return true;
+}
+
 // S <- PP^{-1} given U (PP = U'U): S starts as I; lane c solves U'y = e_c then U x = y on its own
 // column of S (dot-product form, ascending k as the reference's trsm), four products in flight.
 __device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int lane)
@@ -1362,7 +1412,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (t < 64) {
     // ================= wave 0: the dense stage, alone, no workgroup barriers =================
     const int lane = t;
-    bool ok = w_chol_upper(A, P, ld, lane);                                   // U = chol(PP,'U')
+    bool ok = w_chol_reg<false>(A, P, ld, lane, recL);                        // U = chol(PP,'U') (recL is idle until the sweeps)
     if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
     if (ok && need_inverse) {
       w_inverse_from_U(A, S, P, ld, lane);                                     // S = PP^{-1}
