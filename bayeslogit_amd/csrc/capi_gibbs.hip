@@ -191,6 +191,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
     fprintf(stderr, "beta stage (us): chol %.1f inverse %.1f rest of dense (wave 0; waves 1-3 generate randoms) %.1f scan tables %.1f serial %.1f\n",
             (st[3] - st[0]) / 100.0, st[4] ? (st[4] - st[3]) / 100.0 : 0.0, (st[5] - (st[4] ? st[4] : st[3])) / 100.0,
             st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
+    if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }
   return BL_OK;
 }

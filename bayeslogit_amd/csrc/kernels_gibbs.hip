@@ -1249,9 +1249,8 @@ __device__ bool w_chol_lower(double* S, int P, int ld, int lane)
 // a_ij -= u_ki u_kj, k ascending (a product of the same two numbers either way round) -- so the factor is
 // bit-identical; LOWER = false: A = U'U, reads and writes the upper triangle of M; LOWER = true: M = L L', reads
 // the lower triangle of M (row i of the transposed problem is column i of the lower triangle), writes L = U'
-// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS.  Measured in k_beta64: the upper form
-// 65 us against w_chol_upper's 130; the lower form is SLOWER than w_chol_lower (whose row-per-lane LDS accesses
-// are already conflict-free), so only <false> is used.
+// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS.  Measured in k_beta64: 65 us each
+// against 130 for w_chol_upper / w_chol_lower.
 template <bool LOWER>
 __device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
 {
@@ -1438,7 +1437,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         double m = lane < P ? a.bP[lane] : 0.0;
         m = w_solve_Ut_vec(A, m, P, ld, lane);
         m = w_solve_U_vec(A, m, P, ld, lane);                                 // mP
-        ok = w_chol_lower(S, P, ld, lane);                                    // L = chol(S,'L')
+        if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
+        ok = w_chol_reg<true>(S, P, ld, lane, recL);                          // L = chol(S,'L')
+        if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
         if (ok) {
           // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0,
           // A (U is dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the ballots ignore NaN
