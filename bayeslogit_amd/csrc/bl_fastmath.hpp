@@ -1,6 +1,6 @@
 // bl_fastmath.hpp -- fp64 log and exp for the samplers' inner loops.
 // ocml's log(double) is ~98 VALU instructions on gfx950 and exp ~42 (measured from the ISA);
-// the transition body of the PG state machine calls both for every uniform, so they are the
+// the attempt body of the PG(1,z) sampler (bl_pg1_sm.hpp) calls both for every proposal, so they are the
 // largest line items of the draw kernels.  These versions are the classic argument-reduction
 // + short polynomial forms (log: fdlibm e_log.c's s = f/(2+f) series with its Lg1..Lg7
 // coefficients and hi/lo split of ln 2; exp: k ln2 reduction + degree-13 Taylor/Horner on

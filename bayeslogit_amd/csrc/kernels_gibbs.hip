@@ -1,7 +1,7 @@
 // kernels_gibbs.hip -- kernels of the logistic Gibbs sweep on MI355X (gfx950).
 // One sweep over this rank's rows of X (Logit.hpp:426-431) is two streaming passes:
 //   pass 1  k_psi_omega_nb : psi = X beta by coalesced 16-byte loads + a 16-lane butterfly,
-//           then omega ~ PG(n, psi) by the wavefront work-queue state machine (one draw per
+//           then omega ~ PG(n, psi) by the wavefront work queue of bl_pg1_queue.hpp (one draw per
 //           lane, idle lanes refilled by ballot / prefix count); writes omega (8 B/row).
 //   pass 2  k_xwx_mfma     : X' Omega X as a rank-N update on the fp64 matrix pipe
 //           (v_mfma_f64_16x16x4_f64, upper-triangle 16x16 blocks), 2 waves per SIMD.
