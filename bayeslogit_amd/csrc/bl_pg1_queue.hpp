@@ -41,8 +41,11 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
                                                   const double* __restrict__ sM, double* __restrict__ x,
                                                   const NT* __restrict__ nvec, int nscalar, int64_t base,
                                                   uint64_t idx0, uint32_t epoch, uint32_t k0, uint32_t k1,
-                                                  uint64_t lt_mask, int& st_flags)
+                                                  uint64_t lt_mask, int& st_flags,
+                                                  const uint32_t* __restrict__ rowoff = nullptr)
 {
+  // rowoff (or null): the observation of list entry `slot` is row base + rowoff[slot] instead of base + slot
+  // (a list gathered from scattered rows; z, mass and n are still indexed by slot)
   int next = 0;      // wave-uniform: first unstarted entry of the list
   for (;;) {
     const bool idle = L.row < 0;
@@ -51,14 +54,15 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
       const int cand = next + __popcll(im & lt_mask);
       if (idle && cand < cnt) {
         const int slot = list[cand];
-        int n = nvec ? (int)(NLDS ? nvec[slot] : nvec[base + slot]) : nscalar;      // (int) n(i), Logit.hpp:287
+        const int64_t row = base + (rowoff ? (int64_t)rowoff[slot] : (int64_t)slot);
+        int n = nvec ? (int)(NLDS ? nvec[slot] : nvec[row]) : nscalar;              // (int) n(i), Logit.hpp:287
         if (n < 1) { n = 1; st_flags |= ST_BAD_SHAPE; }       // PolyaGamma.cpp:128-135 (NTHROW)
-        L.row = base + slot;
+        L.row = row;
         L.nrem = n;
-        L.par.Z = fabs(ZSRC == 2 ? z[slot] : ZSRC == 1 ? x[base + slot] : z[base + slot]) * 0.5;
+        L.par.Z = fabs(ZSRC == 2 ? z[slot] : ZSRC == 1 ? x[row] : z[row]) * 0.5;
         L.par.mass = sM[slot];
         pg1_par_finish(L.par);
-        const uint64_t idx = idx0 + (uint64_t)(base + slot);
+        const uint64_t idx = idx0 + (uint64_t)row;
         L.c0 = (uint32_t)idx;
         L.c1 = ctr1_of(idx, DOM_DRAW);
         L.blk = 0;

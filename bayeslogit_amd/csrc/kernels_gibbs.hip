@@ -121,27 +121,71 @@ __device__ __forceinline__ T* uniptr(T* p) { return reinterpret_cast<T*>(uni64(r
 
 // (arguments of an out-of-line device function arrive in VGPRs; all but lt_mask are wave-uniform and
 // are moved back to SGPRs first.)  Returns the sampler status flags of the chunk.
-__device__ __attribute__((noinline)) int draw_chunk(const unsigned short* listA_, int nA_,
-                                                    const unsigned short* listB_, int nB_, const double* sZw_,
+template <int ZC>
+__device__ __attribute__((noinline)) int draw_chunk(const unsigned short* list_, int n_, const double* sZw_,
                                                     const double* sMw_, const int* sNw_, double* w_, int64_t base_,
                                                     uint64_t idx0_, uint32_t epoch_, uint32_t k0_, uint32_t k1_,
                                                     uint64_t lt_mask)
 {
-  const unsigned short* listA = uniptr(listA_);
-  const unsigned short* listB = uniptr(listB_);
+  const unsigned short* list = uniptr(list_);
   const double* sZw = uniptr(sZw_);
   const double* sMw = uniptr(sMw_);
   const int* sNw = uniptr(sNw_);
   double* w = uniptr(w_);
-  const int nA = (int)uni32((uint32_t)nA_), nB = (int)uni32((uint32_t)nB_);
+  const int n = (int)uni32((uint32_t)n_);
   const int64_t base = (int64_t)uni64((uint64_t)base_);
   const uint64_t idx0 = uni64(idx0_);
   const uint32_t epoch = uni32(epoch_), k0 = uni32(k0_), k1 = uni32(k1_);
   int st_flags = 0;
-  if (nA > 0)
-    devroye_queue<1, 2, int, true>(listA, nA, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
-  if (nB > 0)
-    devroye_queue<2, 2, int, true>(listB, nB, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+  devroye_queue<ZC, 2, int, true>(list, n, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+  return st_flags;
+}
+
+// The |psi|/2 >= 1/t rows are rare in a Gibbs sweep (0.5 % at C4) but their sampler is the heavy one, and an
+// out-of-line call that uses most of the register file saves ~110 callee-saved registers per lane to scratch:
+// paid once per 512-row chunk that was 1 GB of scratch traffic per pass.  Such rows are therefore DEFERRED:
+// phase 1 parks their psi in w[] and their row offset in a per-wave LDS list, and this function draws the
+// whole list at once (when it fills, and at the end of the wave's range), re-using the chunk's LDS arrays.
+constexpr int kDefCap = 1024;    // >= 2 kSuper: a chunk adds at most kSuper entries and the list is flushed above kDefCap - kSuper
+__device__ __attribute__((noinline)) int draw_deferred(const uint32_t* list_, int nd_, double* sZw_, double* sMw_,
+                                                       int* sNw_, unsigned short* sIdxw_, double* w_,
+                                                       const double* nvec_, int64_t r0_, uint64_t idx0_,
+                                                       uint32_t epoch_, uint32_t k0_, uint32_t k1_, uint64_t lt_mask)
+{
+  const uint32_t* list = uniptr(list_);
+  double* sZw = uniptr(sZw_);
+  double* sMw = uniptr(sMw_);
+  int* sNw = uniptr(sNw_);
+  unsigned short* sIdxw = uniptr(sIdxw_);
+  double* w = uniptr(w_);
+  const double* nvec = uniptr(nvec_);
+  const int nd = (int)uni32((uint32_t)nd_);
+  const int64_t r0 = (int64_t)uni64((uint64_t)r0_);
+  const uint64_t idx0 = uni64(idx0_);
+  const uint32_t epoch = uni32(epoch_), k0 = uni32(k0_), k1 = uni32(k1_);
+  const int lane = threadIdx.x & 63;
+  int st_flags = 0;
+  for (int seg = 0; seg < nd; seg += kSuper) {            // the chunk arrays hold kSuper entries at a time
+    const int n = (nd - seg) < kSuper ? (nd - seg) : kSuper;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < n) {
+        const int64_t row = r0 + (int64_t)list[seg + i];
+        const double psi = w[row];
+        const double Z = fabs(psi) * 0.5;
+        sZw[i] = psi;
+        sMw[i] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
+        sNw[i] = (int)nvec[row];                            // (int) n(i), Logit.hpp:287
+        sIdxw[i] = (unsigned short)i;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Pg1Slot L;
+    devroye_queue_run<2, 2, int, true>(L, true, sIdxw, n, sZw, sMw, w, sNw, 1, r0, idx0, epoch, k0, k1, lt_mask, st_flags,
+                                       list + seg);
+    __builtin_amdgcn_wave_barrier();
+  }
   return st_flags;
 }
 
@@ -157,12 +201,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
   __shared__ double sM[kBlock / 64][kSuper];
   __shared__ double sZ[kBlock / 64][kSuper];
   __shared__ int sN[kBlock / 64][kSuper];
-  __shared__ unsigned short sIdx[kBlock / 64][kSuper];   // class 1 from the front, class 2 from the back
+  __shared__ unsigned short sIdx[kBlock / 64][kSuper];   // the chunk's class-1 rows
+  __shared__ uint32_t sDef[kBlock / 64][kDefCap];        // deferred class-2 rows (offsets from the wave's first row)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, c = lane & 15;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   int st_flags = 0;
+  int nDef = 0;                                          // wave-uniform
   double bq[NB];
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -177,7 +223,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
   const int64_t r1 = (r0 + per_wave) < N ? (r0 + per_wave) : N;
   for (int64_t base = r0; base < r1;) {
     const int cnt = (int)((r1 - base) < chunk ? (r1 - base) : chunk);
-    int nA = 0, nB = 0;   // wave-uniform list lengths
+    int nA = 0;           // wave-uniform list length
     // phase 1: psi for the rows of the chunk, 64 rows (16 groups) at a time
     for (int t0 = 0; t0 < cnt; t0 += 64) {
       double psi = 0.0;
@@ -201,11 +247,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
         if (off) psi -= off[base + slot];
         if (MODE == blk::W_DRAW) {
           const double Z = fabs(psi) * 0.5;                     // PolyaGamma.cpp:154
-          sZ[wave][slot] = psi;
-          sM[wave][slot] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);   // right for |psi|/2 < 1/t
-          sN[wave][slot] = (int)nvec[base + slot];              // (int) n(i), Logit.hpp:287
           small = kSmTRecip > Z;                // PolyaGamma.cpp:87
           large = !small;
+          if (small) {
+            sZ[wave][slot] = psi;
+            sM[wave][slot] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);
+            sN[wave][slot] = (int)nvec[base + slot];            // (int) n(i), Logit.hpp:287
+          } else {
+            w[base + slot] = psi;                               // parked until the deferred list is drawn
+          }
         } else {
           w[base + slot] = weight_of<MODE>(psi, nvec[base + slot], seed, 0, epoch, st_flags);
         }
@@ -213,30 +263,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
       if (MODE == blk::W_DRAW) {
         const uint64_t ma = __ballot(small), mb = __ballot(large);
         if (small) sIdx[wave][nA + __popcll(ma & lt_mask)] = (unsigned short)slot;
-        if (large) sIdx[wave][kSuper - 1 - (nB + __popcll(mb & lt_mask))] = (unsigned short)slot;
+        if (large) sDef[wave][nDef + __popcll(mb & lt_mask)] = (uint32_t)(base + slot - r0);
         nA += __popcll(ma);
-        nB += __popcll(mb);
+        nDef += __popcll(mb);
       }
     }
     if (MODE != blk::W_DRAW) { base += cnt; continue; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // LDS lists complete; parked psi stores have left
     __builtin_amdgcn_wave_barrier();
-    // the few |psi|/2 >= 1/t rows, now contiguous in their list, get the general mass
-    for (int i0 = 0; i0 < nB; i0 += 64) {
-      const int i = i0 + lane;
-      if (i < nB) {
-        const int slot = sIdx[wave][kSuper - nB + i];
-        const double Z = fabs(sZ[wave][slot]) * 0.5;
-        sM[wave][slot] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // phase 2: work queue per class
-    st_flags |= draw_chunk(&sIdx[wave][0], nA, &sIdx[wave][kSuper - nB], nB, sZ[wave], sM[wave], sN[wave], w, base,
-                           idx0, epoch, k0, k1, lt_mask);
-    __builtin_amdgcn_wave_barrier();
+    // phase 2: the work queue over the chunk's class-1 rows; the deferred class-2 rows when their list could
+    // not take another chunk's worth, and after the wave's last chunk
+    if (nA > 0)
+      st_flags |= draw_chunk<1>(&sIdx[wave][0], nA, sZ[wave], sM[wave], sN[wave], w, base, idx0, epoch, k0, k1, lt_mask);
     base += cnt;
+    if (nDef > 0 && (nDef > kDefCap - kSuper || base >= r1)) {
+      st_flags |= draw_deferred(sDef[wave], nDef, sZ[wave], sM[wave], sN[wave], sIdx[wave], w, nvec, r0, idx0, epoch, k0, k1,
+                                lt_mask);
+      nDef = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (st_flags) atomicOr(status, st_flags);
 }

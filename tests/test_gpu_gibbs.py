@@ -82,6 +82,33 @@ def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     g.close()
 
 
+@pytest.mark.parametrize("scale,P", [(6.0, 64), (25.0, 64), (6.0, 48), (25.0, 130)])
+def test_sweep_with_many_large_psi_rows(gpu, oracle, scale, P):
+    """Rows with |psi|/2 >= 1/t take the other left-piece sampler and, in the psi/omega pass, a deferred list
+    (flushed when it could not take another chunk, and at the end of a wave's range).  With beta scaled up a
+    third to nearly all of the rows are such rows: omega and X'Omega X against the oracle, shapes n up to 3,
+    enough rows that a wave flushes more than once."""
+    from bayeslogit_amd import device as D
+    N = 60000
+    X, y, n = synth(N, P, 11 + P, nmax=3)
+    beta0 = np.linspace(-1.0, 1.0, P) * scale
+    frac = np.mean(np.abs(X @ beta0) >= 3.125)
+    assert frac > (0.3 if scale < 10 else 0.8)
+    g = shard_of(X, y, n, gpu, seed=5, idx0=77)
+    g.set_beta(beta0)
+    w = torch.zeros(N, dtype=torch.float64, device=gpu)
+    g.sweep_local(2, w)
+    D.sync_status()
+    PPo, wo = oracle.sweep_partial(X, n, beta0, 5, 2, 77)
+    wg = w.cpu().numpy()
+    rel = np.abs(wg - wo) / np.abs(wo)
+    assert (rel > 1e-10).sum() <= 1e-5 * N + 1, rel.max()
+    PP = g.pp().cpu().numpy().reshape(P, P)
+    if (rel > 1e-10).sum() == 0:
+        assert np.abs(PP - PPo).max() <= 1e-12 * np.abs(PPo).max()
+    g.close()
+
+
 def test_kernel_paths_agree_on_padded_data(gpu):
     """The same data with zero columns appended takes different kernels: P = 64 the register-tile MFMA
     kernels on 16-byte loads, P = 63+1 zero... P = 65 the LDS-tile MFMA kernel with masked 8-byte loads
