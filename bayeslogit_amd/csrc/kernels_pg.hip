@@ -350,6 +350,26 @@ int check_args(const void* a, const void* b, int64_t num)
   return BL_OK;
 }
 
+// ------------------------------------------------ diagnostic: sustained v_mfma_f64_16x16x4_f64 rate
+// Ten independent accumulators per wave (the X'Omega X pass's count), no memory traffic.  bench.py quotes the
+// measured rate next to that pass's: the matrix pipe sustains well under its nominal 78.6 TFLOP/s.
+typedef double diag_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_diag_mfma_f64(double* __restrict__ out, int iters, double a0, double b0)
+{
+  diag_d4 acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = diag_d4{0.0, 0.0, 0.0, 0.0};
+  const double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 }  // namespace
 
 // =============================================================== Part 2 (device)
@@ -460,6 +480,28 @@ int bl_fill_shape_dev(double* out, int64_t num, int kmax, uint64_t seed, uint32_
   hipLaunchKernelGGL(k_fill_shape, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, (hipStream_t)stream,
                      out, num, kmax, seed, epoch, idx0);
   BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+int bl_diag_mfma_f64_dev(double* work, int64_t work_doubles, int waves_per_simd, int iters, double* flops,
+                         void* stream)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  if (!work || !flops || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) {
+    blh::set_error("bl_diag_mfma_f64_dev: bad argument");
+    return BL_ERR_ARG;
+  }
+  int dev = 0, cus = 0;
+  BL_HIP_TRY(hipGetDevice(&dev));
+  BL_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = cus * waves_per_simd;      // 256-thread workgroups: one wave on each SIMD of a CU
+  if (work_doubles < (int64_t)grid * 256) {
+    blh::set_error("bl_diag_mfma_f64_dev: work buffer too small");
+    return BL_ERR_ARG;
+  }
+  hipLaunchKernelGGL(k_diag_mfma_f64, dim3(grid), dim3(256), 0, (hipStream_t)stream, work, iters, 1.0, 1.0);
+  BL_HIP_TRY(hipGetLastError());
+  *flops = (double)grid * 4.0 * (double)iters * 10.0 * 2048.0;   // 16*16*4 multiply-adds per instruction
   return BL_OK;
 }
 

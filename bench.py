@@ -236,6 +236,17 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
                 "note": "whole sweep time (both passes) against the fp64 MFMA peak; X' Omega X alone is "
                         "k_xwx_mfma_big in profiles/"}
     roof["kernel_ms"] = sk
+    # the fp64 matrix pipe as measured on this GPU (register-only MFMA loop, 2 waves/SIMD): the X'Omega X pass
+    # cannot take less than its flops at that rate
+    tri_b = (P // 16) * (P // 16 + 1) // 2 if P % 16 == 0 else ((P + 15) // 16) * ((P + 15) // 16 + 1) // 2
+    xwx_flops = 2.0 * nl * tri_b * 256
+    sustained = D.mfma_f64_sustained_tflops(2)
+    roof["mfma_f64"] = {"sustained_tflops_measured": sustained, "nominal_tflops": FP64_MFMA_PEAK_TFLOPS,
+                        "xwx_flops_per_sweep": xwx_flops, "xwx_ms_at_sustained": xwx_flops / (sustained * 1e12) * 1e3,
+                        "note": "pass 2 (X' Omega X on v_mfma_f64_16x16x4_f64) is bounded by this, not by HBM; its "
+                                "measured average is in profiles/ (kernel stats)"}
+    if roof["bound"] == "mfma":
+        roof["frac_of_sustained"] = roof["achieved"] / sustained
     outg = {
         "metric": "Gibbs sweeps/sec", "workload": f"{tag}: logit Gibbs N={N}, P={P}, fp64, omega not stored, "
         f"rows sharded over {world} GPU(s), one P*P all-reduce per sweep",

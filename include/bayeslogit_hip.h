@@ -123,6 +123,11 @@ int bl_fill_norm_dev(double *out, int64_t num, double mean, double sd,
 /* h[i] = 1 + (Philox word mod kmax) : integer shapes 1..kmax as doubles */
 int bl_fill_shape_dev(double *out, int64_t num, int kmax,
                       uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);
+/* diagnostic (bench.py's roofline): one launch of a register-only loop of `iters` x 10 independent
+ * v_mfma_f64_16x16x4_f64 per wave, `waves_per_simd` (1..8) waves on every SIMD; *flops = the flops that launch
+ * performs (the caller times it with events on `stream`).  work: >= CUs * waves_per_simd * 256 doubles. */
+int bl_diag_mfma_f64_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
+                         void *stream);
 /* y[i] ~ Bernoulli(sigmoid(x_i . beta)) for a P x N column-major tX */
 int bl_fill_logit_y_dev(double *y, const double *tX, const double *beta, int64_t N, int P,
                         uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);

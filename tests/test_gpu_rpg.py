@@ -242,3 +242,17 @@ def test_full_size_C3_properties(gpu):
         k = int(m.sum())
         err = (x[m] - mean_i[m]).mean().item()
         assert abs(err) < 6 * np.sqrt(var_i[m].mean().item() / k), b
+
+
+def test_matrix_pipe_diagnostic(gpu):
+    """bl_diag_mfma_f64_dev (the rate bench.py quotes beside the X'Omega X pass): a plausible fp64 rate, and
+    the argument checks."""
+    from bayeslogit_amd import _lib, device as D
+    tf = D.mfma_f64_sustained_tflops(2, iters=500)
+    assert 5.0 < tf < 200.0
+    fl = C.c_double(0.0)
+    work = torch.empty(64, dtype=torch.float64, device=gpu)
+    rc = _lib.lib().bl_diag_mfma_f64_dev(work.data_ptr(), work.numel(), 2, 10, C.byref(fl), None)
+    assert rc != 0          # work buffer too small
+    rc = _lib.lib().bl_diag_mfma_f64_dev(work.data_ptr(), work.numel(), 0, 10, C.byref(fl), None)
+    assert rc != 0
