@@ -1578,63 +1578,115 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   const bool serial = t < 64;
   const bool row = serial && lane < P;
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j
-  double zj = row ? zz[lane] : 0.0;                // z_j
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
+  bool spec_on = true;
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
     if (!serial) {
       if (k + 1 < P) {
+        // all of a thread's loads are issued before the first is stored (one load in flight per thread made
+        // the staging, not the moves, the length of a scan: 7 round trips to L2 per scan)
         double* Rn = recL + ((k + 1) & 1) * nrec;
         const double* src = rec + (size_t)(k + 1) * nrec;
-        for (int e = t - 64; e < nrec; e += kBlock - 64) Rn[e] = src[e];
+        constexpr int kStage = (64 * kRec + (kBlock - 64) - 1) / (kBlock - 64);   // P <= 64
+        double v[kStage];
+#pragma unroll
+        for (int q = 0; q < kStage; ++q) {
+          const int e = t - 64 + q * (kBlock - 64);
+          v[q] = e < nrec ? src[e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kStage; ++q) {
+          const int e = t - 64 + q * (kBlock - 64);
+          if (e < nrec) Rn[e] = v[q];
+        }
       }
     } else {
-      // everything move i+1 needs that does not depend on move i is fetched while move i computes
+      // Moves are taken kGroup at a time, SPECULATIVELY on the fast path: every move of the group is assumed
+      // to take attempt 0's normal s (which is what a move whose bounds contain 0, are wider than sqrt(2 pi)
+      // and contain s does).  The group is straight-line code: all of its loads and broadcasts are issued
+      // first, the only dependent chain is one FMA per move (bs), and each move's test -- every lane's lower
+      // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests of the
+      // move-by-move path -- only ORs compare masks into a scalar.  One branch per group confirms; a group
+      // with a move that fails the test (a few % of the groups on C4) is redone move by move, with all three
+      // tests and the full tnorm, from the state at its start.  Same values either way.
+      // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
+      // moves are gathered at its start (z1v) and a group's new values are scattered at its end.
       const int g4 = (lane < 5 ? lane : 0) * 4;
-      int c_n = __builtin_amdgcn_readfirstlane(ptab[k * P]);
-      int c_nn = ptab[k * P + (P > 1 ? 1 : 0)];                    // two moves ahead (still a VGPR)
       const double qnan = __builtin_nan("");
-      const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
-      double l1_n = row ? L_(S, lr, c_n) : 0.0, rl_n = row ? L_(Ri, lr, c_n) : qnan, rh_n = row ? L_(A, lr, c_n) : qnan;
-      double q0 = Rk[g4], q1 = Rk[g4 + 1], q2 = Rk[g4 + 2], q3 = Rk[g4 + 3];
-      for (int i = 0; i < P; ++i) {
-        const int c = c_n;
-        const double l1 = l1_n, rl = rl_n, rh = rh_n;
-        const double r0 = q0, r1 = q1, r2 = q2, r3 = q3;
-        if (i + 1 < P) {
-          c_n = __builtin_amdgcn_readfirstlane(c_nn);
-          c_nn = ptab[k * P + (i + 2 < P ? i + 2 : i + 1)];
-          l1_n = row ? L_(S, lr, c_n) : 0.0;
-          rl_n = row ? L_(Ri, lr, c_n) : qnan;
-          rh_n = row ? L_(A, lr, c_n) : qnan;
-          const double* Rn = Rk + (i + 1) * kRec + g4;
-          q0 = Rn[0];
-          q1 = Rn[1];
-          q2 = Rn[2];
-          q3 = Rn[3];
+      const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
+      const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
+      const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
+      const double dzv = svec - z1v;
+      constexpr int kGroup = 8;
+      int nfail = 0;
+      for (int i0 = 0; i0 < P; i0 += kGroup) {
+        const int ng = P - i0 < kGroup ? P - i0 : kGroup;
+        const bool spec = spec_on && ng == kGroup;                   // a short last group goes move by move
+        bool ok_l = true;
+        double bs = bj;
+        if (spec && row) {
+          int cc[kGroup];
+          double sg[kGroup], zg[kGroup], dg[kGroup], lg[kGroup], rlg[kGroup], rhg[kGroup];
+#pragma unroll
+          for (int u = 0; u < kGroup; ++u) {
+            cc[u] = __builtin_amdgcn_readlane(cvec, i0 + u);
+            sg[u] = readlane_f64(svec, i0 + u);
+            zg[u] = readlane_f64(z1v, i0 + u);
+            dg[u] = readlane_f64(dzv, i0 + u);
+            lg[u] = L_(S, lane, cc[u]);
+            rlg[u] = L_(Ri, lane, cc[u]);
+            rhg[u] = L_(A, lane, cc[u]);
+          }
+          uint64_t acc = 0ull;
+#pragma unroll
+          for (int u = 0; u < kGroup; ++u) {
+            const double lo = zg[u] - bs * rlg[u];                     // NaN: this row does not bound the move from below
+            const double hi = zg[u] - bs * rhg[u];
+            // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit
+            acc |= __builtin_amdgcn_fcmp(lo, sg[u], 2) | __builtin_amdgcn_fcmp(hi, sg[u], 4) |
+                   __builtin_amdgcn_fcmp(lo, -1.26, 2) | __builtin_amdgcn_fcmp(hi, 1.26, 4);   // 2: ogt, 4: olt
+            bs += lg[u] * dg[u];
+          }
+          ok_l = acc == 0ull;
         }
-        const double z1 = readlane_f64(zj, c);
-        double lo = z1 - bj * rl;                                    // NaN: this row does not bound the move from below
-        double hi = z1 - bj * rh;
-        const double s = readlane_f64(r3, 0);                        // attempt 0's normal
-        const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
-        const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
-        const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
-        double z2 = s;
-        if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
-              __ballot(lo > l2s || hi < h0) == 0ull)) {
-          wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
-          lo = lo == lo ? lo : -inf;
-          hi = hi == hi ? hi : inf;
-          z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+        if (spec && __ballot(!ok_l) == 0ull) {                       // wave-uniform: all lanes take the same side
+          bj = bs;
+          if (row && lane >= i0 && lane < i0 + kGroup) zz[cvec] = svec;
+          continue;
         }
-        const double dz = z2 - z1;
-        bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
-        zj = lane == c ? z2 : zj;
+        ++nfail;
+        const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
+        for (int i = i0; i < i0 + ng; ++i) {
+          const int c = __builtin_amdgcn_readlane(cvec, i);
+          const double l1 = row ? L_(S, lr, c) : 0.0, rl = row ? L_(Ri, lr, c) : qnan, rh = row ? L_(A, lr, c) : qnan;
+          const double* Rn = Rk + i * kRec + g4;
+          const double r0 = Rn[0], r1 = Rn[1], r2 = Rn[2], r3 = Rn[3];
+          const double z1 = readlane_f64(z1v, i);
+          double lo = z1 - bj * rl;
+          double hi = z1 - bj * rh;
+          const double s = readlane_f64(r3, 0);                        // attempt 0's normal
+          const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
+          const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
+          const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
+          double z2 = s;
+          if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
+                __ballot(lo > l2s || hi < h0) == 0ull)) {
+            wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
+            lo = lo == lo ? lo : -inf;
+            hi = hi == hi ? hi : inf;
+            z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+          }
+          const double dz = z2 - z1;
+          bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
+          if (lane == 0) zz[c] = z2;
+        }
       }
+      // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
+      spec_on = 2 * nfail * kGroup < P || ((k + 1) & 7) == 0;
     }
     __syncthreads();
   }
