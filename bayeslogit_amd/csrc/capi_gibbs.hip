@@ -178,19 +178,20 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
   static const bool dbg = getenv("BL_BETA_DEBUG") != nullptr;   // development aid: phase timing of the beta stage
   static unsigned long long* dbuf = nullptr;
   if (dbg) {
-    if (!dbuf) (void)hipMalloc((void**)&dbuf, 8 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dbuf, 0, 8 * sizeof(unsigned long long), h->stream);
+    if (!dbuf) (void)hipMalloc((void**)&dbuf, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), h->stream);
     a.dbg = dbuf;
   }
   blk::launch_beta(a, constrain ? blk::B_CONSTRAINED : blk::B_MVN, h->stream);
   BL_HIP_TRY(hipGetLastError());
   if (dbg) {
-    unsigned long long st[8];
+    unsigned long long st[16];
     (void)hipMemcpyAsync(st, dbuf, sizeof(st), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
     fprintf(stderr, "beta stage (us): chol %.1f inverse %.1f rest of dense (wave 0; waves 1-3 generate randoms) %.1f scan tables %.1f serial %.1f\n",
             (st[3] - st[0]) / 100.0, st[4] ? (st[4] - st[3]) / 100.0 : 0.0, (st[5] - (st[4] ? st[4] : st[3])) / 100.0,
             st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
+    if (st[7]) fprintf(stderr, "  groups of moves redone move by move: %llu\n", st[8]);
     if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }
   return BL_OK;

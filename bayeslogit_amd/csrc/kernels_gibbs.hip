@@ -1401,6 +1401,45 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
   return b;
 }
 
+// One speculative group of the constrained sweeps (see k_beta64): beta after each of the group's moves on the
+// fast path (bs_out: after all of them) and the bound test of moves 2W and 2W+1 of the group.  Returns true if
+// both pass in every lane.
+constexpr int kSpecGroup = 8;
+template <int W>
+__device__ __forceinline__ bool spec_group(const double* S, const double* Ri, const double* A, int ld, int lane, int i0,
+                                           int cvec, double svec, double z1v, double dzv, double bj, double& bs_out)
+{
+  int cc[kSpecGroup];
+  double dg[kSpecGroup], lg[kSpecGroup];
+#pragma unroll
+  for (int u = 0; u < kSpecGroup; ++u) {
+    cc[u] = __builtin_amdgcn_readlane(cvec, i0 + u);
+    dg[u] = readlane_f64(dzv, i0 + u);
+    lg[u] = L_(S, lane, cc[u]);
+  }
+  constexpr int ua = 2 * W, ub = 2 * W + 1;
+  const double rla = L_(Ri, lane, cc[ua]), rha = L_(A, lane, cc[ua]);
+  const double rlb = L_(Ri, lane, cc[ub]), rhb = L_(A, lane, cc[ub]);
+  const double sa = readlane_f64(svec, i0 + ua), za = readlane_f64(z1v, i0 + ua);
+  const double sb = readlane_f64(svec, i0 + ub), zb = readlane_f64(z1v, i0 + ub);
+  double bs = bj, ba = bj, bb = bj;
+#pragma unroll
+  for (int u = 0; u < kSpecGroup; ++u) {
+    if (u == ua) ba = bs;
+    if (u == ub) bb = bs;
+    bs += lg[u] * dg[u];
+  }
+  bs_out = bs;
+  const double loa = za - ba * rla, hia = za - ba * rha;           // NaN: this row does not bound the move on that side
+  const double lob = zb - bb * rlb, hib = zb - bb * rhb;
+  // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit; 2: ogt, 4: olt
+  const uint64_t acc = __builtin_amdgcn_fcmp(loa, sa, 2) | __builtin_amdgcn_fcmp(hia, sa, 4) |
+                       __builtin_amdgcn_fcmp(loa, -1.26, 2) | __builtin_amdgcn_fcmp(hia, 1.26, 4) |
+                       __builtin_amdgcn_fcmp(lob, sb, 2) | __builtin_amdgcn_fcmp(hib, sb, 4) |
+                       __builtin_amdgcn_fcmp(lob, -1.26, 2) | __builtin_amdgcn_fcmp(hib, 1.26, 4);
+  return acc == 0ull;
+}
+
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];
@@ -1564,8 +1603,8 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   }
 
   if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
-  // The serial coordinate sweeps run on wave 0; waves 1-3 stage the next scan's random records
-  // from global scratch into LDS meanwhile (one barrier per scan), so a move reads only LDS.
+  // The coordinate sweeps: a move reads only LDS and registers (the next scan's random records travel from
+  // global scratch to LDS while a scan runs: loaded into registers at its start, stored at its end).
   //
   // Fast path.  A move's value is almost always the Box-Muller normal s of its first attempt: the bounds
   // contain 0, are wider than sqrt(2 pi), and s falls inside (tnorm_lanes' first branch, attempt 0).  That
@@ -1574,123 +1613,118 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // and lo <= s <= hi -- three __ballot tests ((a, b) = (1.26, 1.26), (0, 2.51), (2.51, 0): one-sided bounds,
   // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
   // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
-  const int lane = t & 63;
-  const bool serial = t < 64;
-  const bool row = serial && lane < P;
-  double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j
+  //
+  // Speculative groups on four wavefronts.  Moves are taken kGroup = 8 at a time on the fast path: every
+  // move of the group is assumed to take attempt 0's normal s (which is what a move whose bounds contain 0,
+  // are wider than sqrt(2 pi) and contain s does).  A group is straight-line code: its loads and broadcasts
+  // first, one dependent FMA per move (beta after u moves), and a move's test -- every lane's lower
+  // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests above --
+  // only ORs compare masks into a scalar.  One wavefront issues an instruction every ~8 cycles here, so the
+  // FOUR wavefronts of the workgroup (one per SIMD) each keep a replica of beta (lane j = row j), all run
+  // the one-FMA-per-move chain, and each tests two of the eight moves; the verdicts meet in LDS at one
+  // barrier per group.  A group with a failing move (a few per draw on C4) is redone move by move with all
+  // three tests and the full tnorm, by every wavefront alike (same inputs, same arithmetic: the replicas
+  // stay identical without another exchange).  Same values as the move-by-move loop either way.
+  // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
+  // moves are gathered at its start (z1v) and a group's new values are scattered at its end.
+  const int lane = t & 63, wave = t >> 6;
+  const bool row = lane < P;
+  double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
+  __shared__ int gflag[2][4];
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
   bool spec_on = true;
+  unsigned gi = 0;                                 // speculative groups so far (flag slot parity)
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
-    if (!serial) {
-      if (k + 1 < P) {
-        // all of a thread's loads are issued before the first is stored (one load in flight per thread made
-        // the staging, not the moves, the length of a scan: 7 round trips to L2 per scan)
-        double* Rn = recL + ((k + 1) & 1) * nrec;
-        const double* src = rec + (size_t)(k + 1) * nrec;
-        constexpr int kStage = (64 * kRec + (kBlock - 64) - 1) / (kBlock - 64);   // P <= 64
-        double v[kStage];
+    // next scan's records: global -> registers now, -> LDS at the end of this scan
+    constexpr int kStage = (64 * kRec + kBlock - 1) / kBlock;      // P <= 64
+    double stage[kStage];
+    if (k + 1 < P) {
+      const double* src = rec + (size_t)(k + 1) * nrec;
 #pragma unroll
-        for (int q = 0; q < kStage; ++q) {
-          const int e = t - 64 + q * (kBlock - 64);
-          v[q] = e < nrec ? src[e] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < kStage; ++q) {
-          const int e = t - 64 + q * (kBlock - 64);
-          if (e < nrec) Rn[e] = v[q];
-        }
+      for (int q = 0; q < kStage; ++q) {
+        const int e = t + q * kBlock;
+        stage[q] = e < nrec ? src[e] : 0.0;
       }
-    } else {
-      // Moves are taken kGroup at a time, SPECULATIVELY on the fast path: every move of the group is assumed
-      // to take attempt 0's normal s (which is what a move whose bounds contain 0, are wider than sqrt(2 pi)
-      // and contain s does).  The group is straight-line code: all of its loads and broadcasts are issued
-      // first, the only dependent chain is one FMA per move (bs), and each move's test -- every lane's lower
-      // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests of the
-      // move-by-move path -- only ORs compare masks into a scalar.  One branch per group confirms; a group
-      // with a move that fails the test (a few % of the groups on C4) is redone move by move, with all three
-      // tests and the full tnorm, from the state at its start.  Same values either way.
-      // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
-      // moves are gathered at its start (z1v) and a group's new values are scattered at its end.
-      const int g4 = (lane < 5 ? lane : 0) * 4;
-      const double qnan = __builtin_nan("");
-      const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
-      const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
-      const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
-      const double dzv = svec - z1v;
-      constexpr int kGroup = 8;
-      int nfail = 0;
-      for (int i0 = 0; i0 < P; i0 += kGroup) {
-        const int ng = P - i0 < kGroup ? P - i0 : kGroup;
-        const bool spec = spec_on && ng == kGroup;                   // a short last group goes move by move
+    }
+    const int g4 = (lane < 5 ? lane : 0) * 4;
+    const double qnan = __builtin_nan("");
+    const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
+    const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
+    const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
+    const double dzv = svec - z1v;
+    int nfail = 0;
+    for (int i0 = 0; i0 < P; i0 += kSpecGroup) {
+      const int ng = P - i0 < kSpecGroup ? P - i0 : kSpecGroup;
+      const bool spec = spec_on && ng == kSpecGroup;               // a short last group goes move by move
+      double bs = bj;
+      bool all_ok = false;
+      if (spec) {
         bool ok_l = true;
-        double bs = bj;
-        if (spec && row) {
-          int cc[kGroup];
-          double sg[kGroup], zg[kGroup], dg[kGroup], lg[kGroup], rlg[kGroup], rhg[kGroup];
-#pragma unroll
-          for (int u = 0; u < kGroup; ++u) {
-            cc[u] = __builtin_amdgcn_readlane(cvec, i0 + u);
-            sg[u] = readlane_f64(svec, i0 + u);
-            zg[u] = readlane_f64(z1v, i0 + u);
-            dg[u] = readlane_f64(dzv, i0 + u);
-            lg[u] = L_(S, lane, cc[u]);
-            rlg[u] = L_(Ri, lane, cc[u]);
-            rhg[u] = L_(A, lane, cc[u]);
+        if (row) {
+          switch (wave) {
+            case 0: ok_l = spec_group<0>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
+            case 1: ok_l = spec_group<1>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
+            case 2: ok_l = spec_group<2>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
+            default: ok_l = spec_group<3>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
           }
-          uint64_t acc = 0ull;
-#pragma unroll
-          for (int u = 0; u < kGroup; ++u) {
-            const double lo = zg[u] - bs * rlg[u];                     // NaN: this row does not bound the move from below
-            const double hi = zg[u] - bs * rhg[u];
-            // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit
-            acc |= __builtin_amdgcn_fcmp(lo, sg[u], 2) | __builtin_amdgcn_fcmp(hi, sg[u], 4) |
-                   __builtin_amdgcn_fcmp(lo, -1.26, 2) | __builtin_amdgcn_fcmp(hi, 1.26, 4);   // 2: ogt, 4: olt
-            bs += lg[u] * dg[u];
-          }
-          ok_l = acc == 0ull;
         }
-        if (spec && __ballot(!ok_l) == 0ull) {                       // wave-uniform: all lanes take the same side
-          bj = bs;
-          if (row && lane >= i0 && lane < i0 + kGroup) zz[cvec] = svec;
-          continue;
-        }
-        ++nfail;
-        const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
-        for (int i = i0; i < i0 + ng; ++i) {
-          const int c = __builtin_amdgcn_readlane(cvec, i);
-          const double l1 = row ? L_(S, lr, c) : 0.0, rl = row ? L_(Ri, lr, c) : qnan, rh = row ? L_(A, lr, c) : qnan;
-          const double* Rn = Rk + i * kRec + g4;
-          const double r0 = Rn[0], r1 = Rn[1], r2 = Rn[2], r3 = Rn[3];
-          const double z1 = readlane_f64(z1v, i);
-          double lo = z1 - bj * rl;
-          double hi = z1 - bj * rh;
-          const double s = readlane_f64(r3, 0);                        // attempt 0's normal
-          const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
-          const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
-          const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
-          double z2 = s;
-          if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
-                __ballot(lo > l2s || hi < h0) == 0ull)) {
-            wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
-            lo = lo == lo ? lo : -inf;
-            hi = hi == hi ? hi : inf;
-            z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
-          }
-          const double dz = z2 - z1;
-          bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
-          if (lane == 0) zz[c] = z2;
-        }
+        const bool okw = __ballot(!ok_l) == 0ull;                  // this wavefront's two moves
+        if (lane == 0) gflag[gi & 1][wave] = okw ? 0 : 1;
+        __syncthreads();
+        const int* gf = gflag[gi & 1];
+        all_ok = __builtin_amdgcn_readfirstlane(gf[0] | gf[1] | gf[2] | gf[3]) == 0;
+        ++gi;
       }
-      // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
-      spec_on = 2 * nfail * kGroup < P || ((k + 1) & 7) == 0;
+      if (all_ok) {
+        bj = bs;
+        if (wave == 0 && row && lane >= i0 && lane < i0 + kSpecGroup) zz[cvec] = svec;
+        continue;
+      }
+      ++nfail;
+      const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
+      for (int i = i0; i < i0 + ng; ++i) {
+        const int c = __builtin_amdgcn_readlane(cvec, i);
+        const double l1 = row ? L_(S, lr, c) : 0.0, rl = row ? L_(Ri, lr, c) : qnan, rh = row ? L_(A, lr, c) : qnan;
+        const double* Rn = Rk + i * kRec + g4;
+        const double r0 = Rn[0], r1 = Rn[1], r2 = Rn[2], r3 = Rn[3];
+        const double z1 = readlane_f64(z1v, i);
+        double lo = z1 - bj * rl;                                    // NaN: this row does not bound the move from below
+        double hi = z1 - bj * rh;
+        const double s = readlane_f64(r3, 0);                        // attempt 0's normal
+        const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
+        const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
+        const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
+        double z2 = s;
+        if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
+              __ballot(lo > l2s || hi < h0) == 0ull)) {
+          wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
+          lo = lo == lo ? lo : -inf;
+          hi = hi == hi ? hi : inf;
+          z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+        }
+        const double dz = z2 - z1;
+        bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
+        if (wave == 0 && lane == 0) zz[c] = z2;
+      }
+    }
+    // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
+    spec_on = 2 * nfail * kSpecGroup < P || ((k + 1) & 7) == 0;
+    if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
+    if (k + 1 < P) {
+      double* Rn = recL + ((k + 1) & 1) * nrec;
+#pragma unroll
+      for (int q = 0; q < kStage; ++q) {
+        const int e = t + q * kBlock;
+        if (e < nrec) Rn[e] = stage[q];
+      }
     }
     __syncthreads();
   }
-  if (row) a.beta_out[lane] = bj;
+  if (wave == 0 && row) a.beta_out[lane] = bj;
   if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
 }
 
