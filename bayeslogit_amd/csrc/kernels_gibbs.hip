@@ -1404,40 +1404,52 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
 // One speculative group of the constrained sweeps (see k_beta64): beta after each of the group's moves on the
 // fast path (bs_out: after all of them) and the bound test of moves 2W and 2W+1 of the group.  Returns true if
 // both pass in every lane.
-constexpr int kSpecGroup = 8;
-template <int W>
+template <int W, int G>
 __device__ __forceinline__ bool spec_group(const double* S, const double* Ri, const double* A, int ld, int lane, int i0,
                                            int cvec, double svec, double z1v, double dzv, double bj, double& bs_out)
 {
-  int cc[kSpecGroup];
-  double dg[kSpecGroup], lg[kSpecGroup];
+  constexpr int M = G / 4, u0 = W * M;          // this wavefront tests moves u0 .. u0 + M - 1 of the group
+  double lg[G];
 #pragma unroll
-  for (int u = 0; u < kSpecGroup; ++u) {
-    cc[u] = __builtin_amdgcn_readlane(cvec, i0 + u);
-    dg[u] = readlane_f64(dzv, i0 + u);
-    lg[u] = L_(S, lane, cc[u]);
+  for (int u = 0; u < G; ++u) lg[u] = L_(S, lane, __builtin_amdgcn_readlane(cvec, i0 + u));
+  double rl[M], rh[M], sm[M], zm[M], bm[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int c = __builtin_amdgcn_readlane(cvec, i0 + u0 + m);
+    rl[m] = L_(Ri, lane, c);
+    rh[m] = L_(A, lane, c);
+    sm[m] = readlane_f64(svec, i0 + u0 + m);
+    zm[m] = readlane_f64(z1v, i0 + u0 + m);
+    bm[m] = bj;
   }
-  constexpr int ua = 2 * W, ub = 2 * W + 1;
-  const double rla = L_(Ri, lane, cc[ua]), rha = L_(A, lane, cc[ua]);
-  const double rlb = L_(Ri, lane, cc[ub]), rhb = L_(A, lane, cc[ub]);
-  const double sa = readlane_f64(svec, i0 + ua), za = readlane_f64(z1v, i0 + ua);
-  const double sb = readlane_f64(svec, i0 + ub), zb = readlane_f64(z1v, i0 + ub);
-  double bs = bj, ba = bj, bb = bj;
+  double bs = bj;
 #pragma unroll
-  for (int u = 0; u < kSpecGroup; ++u) {
-    if (u == ua) ba = bs;
-    if (u == ub) bb = bs;
-    bs += lg[u] * dg[u];
+  for (int u = 0; u < G; ++u) {
+    if (u >= u0 && u < u0 + M) bm[u - u0] = bs;
+    bs += lg[u] * readlane_f64(dzv, i0 + u);
   }
   bs_out = bs;
-  const double loa = za - ba * rla, hia = za - ba * rha;           // NaN: this row does not bound the move on that side
-  const double lob = zb - bb * rlb, hib = zb - bb * rhb;
-  // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit; 2: ogt, 4: olt
-  const uint64_t acc = __builtin_amdgcn_fcmp(loa, sa, 2) | __builtin_amdgcn_fcmp(hia, sa, 4) |
-                       __builtin_amdgcn_fcmp(loa, -1.26, 2) | __builtin_amdgcn_fcmp(hia, 1.26, 4) |
-                       __builtin_amdgcn_fcmp(lob, sb, 2) | __builtin_amdgcn_fcmp(hib, sb, 4) |
-                       __builtin_amdgcn_fcmp(lob, -1.26, 2) | __builtin_amdgcn_fcmp(hib, 1.26, 4);
+  uint64_t acc = 0ull;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double lo = zm[m] - bm[m] * rl[m], hi = zm[m] - bm[m] * rh[m];   // NaN: the row does not bound that side
+    // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit; 2: ogt, 4: olt
+    acc |= __builtin_amdgcn_fcmp(lo, sm[m], 2) | __builtin_amdgcn_fcmp(hi, sm[m], 4) |
+           __builtin_amdgcn_fcmp(lo, -1.26, 2) | __builtin_amdgcn_fcmp(hi, 1.26, 4);
+  }
   return acc == 0ull;
+}
+template <int G>
+__device__ __forceinline__ bool spec_group_w(int wave, const double* S, const double* Ri, const double* A, int ld, int lane,
+                                             int i0, int cvec, double svec, double z1v, double dzv, double bj,
+                                             double& bs_out)
+{
+  switch (wave) {
+    case 0: return spec_group<0, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    case 1: return spec_group<1, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    case 2: return spec_group<2, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    default: return spec_group<3, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
@@ -1603,6 +1615,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   }
 
   if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
+  if (a.dbg && t == 0) a.dbg[9] = clock64();
   // The coordinate sweeps: a move reads only LDS and registers (the next scan's random records travel from
   // global scratch to LDS while a scan runs: loaded into registers at its start, stored at its end).
   //
@@ -1614,14 +1627,14 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
   // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
   //
-  // Speculative groups on four wavefronts.  Moves are taken kGroup = 8 at a time on the fast path: every
+  // Speculative groups on four wavefronts.  Moves are taken 16 (or 8) at a time on the fast path: every
   // move of the group is assumed to take attempt 0's normal s (which is what a move whose bounds contain 0,
   // are wider than sqrt(2 pi) and contain s does).  A group is straight-line code: its loads and broadcasts
   // first, one dependent FMA per move (beta after u moves), and a move's test -- every lane's lower
   // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests above --
   // only ORs compare masks into a scalar.  One wavefront issues an instruction every ~8 cycles here, so the
   // FOUR wavefronts of the workgroup (one per SIMD) each keep a replica of beta (lane j = row j), all run
-  // the one-FMA-per-move chain, and each tests two of the eight moves; the verdicts meet in LDS at one
+  // the one-FMA-per-move chain, and each tests a quarter of the group's moves; the verdicts meet in LDS at one
   // barrier per group.  A group with a failing move (a few per draw on C4) is redone move by move with all
   // three tests and the full tnorm, by every wavefront alike (same inputs, same arithmetic: the replicas
   // stay identical without another exchange).  Same values as the move-by-move loop either way.
@@ -1636,6 +1649,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
   bool spec_on = true;
+  int gmax = 32;                                   // largest group of the scan
   unsigned gi = 0;                                 // speculative groups so far (flag slot parity)
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
@@ -1656,23 +1670,25 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
     const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
     const double dzv = svec - z1v;
-    int nfail = 0;
-    for (int i0 = 0; i0 < P; i0 += kSpecGroup) {
-      const int ng = P - i0 < kSpecGroup ? P - i0 : kSpecGroup;
-      const bool spec = spec_on && ng == kSpecGroup;               // a short last group goes move by move
+    int nfail = 0;                                                 // moves redone move by move in this scan
+    for (int i0 = 0; i0 < P;) {
+      const int left = P - i0;
+      // groups of 32, 16 or 8 moves (a quarter of them tested by each wavefront); a shorter tail goes move by move
+      const int ng = !spec_on ? (left < 8 ? left : 8) : (left >= 32 && gmax >= 32) ? 32 : (left >= 16 && gmax >= 16) ? 16 : left >= 8 ? 8 : left;
+      const bool spec = spec_on && ng >= 8;
       double bs = bj;
       bool all_ok = false;
       if (spec) {
         bool ok_l = true;
         if (row) {
-          switch (wave) {
-            case 0: ok_l = spec_group<0>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
-            case 1: ok_l = spec_group<1>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
-            case 2: ok_l = spec_group<2>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
-            default: ok_l = spec_group<3>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs); break;
-          }
+          if (ng == 32)
+            ok_l = spec_group_w<32>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
+          else if (ng == 16)
+            ok_l = spec_group_w<16>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
+          else
+            ok_l = spec_group_w<8>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
         }
-        const bool okw = __ballot(!ok_l) == 0ull;                  // this wavefront's two moves
+        const bool okw = __ballot(!ok_l) == 0ull;                  // this wavefront's moves
         if (lane == 0) gflag[gi & 1][wave] = okw ? 0 : 1;
         __syncthreads();
         const int* gf = gflag[gi & 1];
@@ -1681,10 +1697,11 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       }
       if (all_ok) {
         bj = bs;
-        if (wave == 0 && row && lane >= i0 && lane < i0 + kSpecGroup) zz[cvec] = svec;
+        if (wave == 0 && row && lane >= i0 && lane < i0 + ng) zz[cvec] = svec;
+        i0 += ng;
         continue;
       }
-      ++nfail;
+      nfail += ng;
       const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
       for (int i = i0; i < i0 + ng; ++i) {
         const int c = __builtin_amdgcn_readlane(cvec, i);
@@ -1710,9 +1727,11 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
         if (wave == 0 && lane == 0) zz[c] = z2;
       }
+      i0 += ng;
     }
     // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
-    spec_on = 2 * nfail * kSpecGroup < P || ((k + 1) & 7) == 0;
+    spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
+    gmax = nfail == 0 ? 32 : 8;                                    // failures come in runs (a coordinate at its bound): small groups then
     if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
     if (k + 1 < P) {
       double* Rn = recL + ((k + 1) & 1) * nrec;
@@ -1726,6 +1745,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   }
   if (wave == 0 && row) a.beta_out[lane] = bj;
   if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
+  if (a.dbg && t == 0) a.dbg[10] = clock64();
 }
 
 // ---- constrained coordinate sweeps for 64 < P <= 256 (Logit.hpp:368-399), same design as k_beta64's:

@@ -82,6 +82,42 @@ def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     g.close()
 
 
+@pytest.mark.parametrize("P", [64, 63, 56, 40, 33, 24, 9, 8, 7])
+@pytest.mark.parametrize("lo,hi", [(0.6, 1.6), (0.0, 0.3), (0.0, 0.02)])
+def test_constrained_draw_group_sizes(gpu, oracle, P, lo, hi):
+    """The constrained draw takes its P^2 coordinate moves in speculative groups of 32, 16 or 8 (a shorter
+    tail and every group with a move that needs the bounds go move by move): every split of P, with
+    beta_prev well inside the constraint region (all groups confirmed), near it, and on it (most groups
+    redone, then speculation switched off) against the oracle's move-by-move draw, several sweeps chained."""
+    from bayeslogit_amd import device as D
+    N = 40 * P
+    X, y, n = synth(N, P, 3 * P + int(100 * hi), nmax=2)
+    m0, P0 = np.zeros(P), np.eye(P) * 0.3
+    beta = np.linspace(lo, hi, P)
+    g = shard_of(X, y, n, gpu, seed=17, idx0=5)
+    g.set_prior(m0, P0)
+    g.set_bp_local()
+    g.finish_bp()
+    bPo = oracle.set_bP(y, X, n, m0, P0)
+    for sweep in range(3):
+        g.set_beta(beta)
+        g.sweep_local(sweep, None)
+        g.draw_beta(sweep, 1)
+        D.sync_status()
+        PPo, _ = oracle.sweep_partial(X, n, beta, 17, sweep, 5)
+        bo = oracle.draw_beta(PPo + P0, bPo, beta, 17, sweep, 1)
+        E = np.random.default_rng(sweep).normal(size=(P, P)) * 1e-15
+        bo2 = oracle.draw_beta((PPo + P0) * (1 + (E + E.T) / 2), bPo, beta, 17, sweep, 1)
+        bg = g.get_beta()
+        assert np.all(bg[:-1] >= -1e-12)
+        if np.abs(bo2 - bo).max() < 1e-10:           # the oracle's own draw is stable here (see the test above)
+            assert np.abs(bg - bo).max() < 1e-9, (sweep, np.abs(bg - bo).max())
+        else:
+            assert lo == 0.0                         # only the draws pressed against the bounds may be unstable
+        beta = bo
+    g.close()
+
+
 @pytest.mark.parametrize("scale,P", [(6.0, 64), (25.0, 64), (6.0, 48), (25.0, 130)])
 def test_sweep_with_many_large_psi_rows(gpu, oracle, scale, P):
     """Rows with |psi|/2 >= 1/t take the other left-piece sampler and, in the psi/omega pass, a deferred list
