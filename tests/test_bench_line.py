@@ -1,0 +1,67 @@
+"""The bench.py output contract, checked on the committed line of the last GPU session
+(profiles/rNN_bench_line.json is bench.py's own stdout, copied by scripts/gpu_round.sh) and on bench.py's
+argument defaults.  No GPU."""
+import glob
+import importlib.util
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert files, "no committed bench line"
+    return json.loads(open(files[-1]).read())
+
+
+def test_contract_keys_and_types():
+    d = _line()
+    for k, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                   ("config", dict)]:
+        assert k in d and isinstance(d[k], typ), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    assert d["metric"].startswith("PG draws/sec") and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert "model" not in d["config"]
+    # value is draws per second over the timed steps
+    draws = d["config"]["draws_per_gpu_per_step"] * d["n_gpus"]
+    assert abs(d["value"] * 1e6 - draws / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] * 1e6
+
+
+def test_roofline_and_cpu_baseline_objects():
+    d = _line()
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]   # measured >= algorithmic
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    g = d["gibbs"]
+    assert g["unit"] == "sweeps/s" and g["value"] == g["constrained"]["sweeps_per_s"]
+    gr = g["roofline"]
+    assert abs(gr["frac"] - gr["achieved"] / gr["peak"]) < 1e-12
+    ch = g["chain"]
+    assert ch["burn"] == 100 and ch["samp"] == 1000 and ch["max_abs_z"] < 5.0       # posterior means near the truth
+
+
+def test_bench_defaults_are_one_gpu_and_short():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(m)
+        a = m.parse()
+    finally:
+        sys.argv = argv
+    assert a.gpus == 1 and a.steps <= 50 and a.warmup <= 10
+    assert a.draws == 100_000_000 and a.gibbs_n == 10_000_000 and a.gibbs_p == 64      # BASELINE configs C2, C4
+    assert a.backend == "nccl"
