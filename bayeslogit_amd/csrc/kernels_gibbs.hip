@@ -1581,6 +1581,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     }
     // swap targets are read back by wave 1 only: make its own and its neighbours' stores visible
     __threadfence_block();
+    if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
     // named barrier among waves 1-3 is not available: scan permutations are built after the
     // workgroup barrier below instead (they are cheap: LDS only)
   }
