@@ -1537,15 +1537,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         ok = w_chol_reg<true>(S, P, ld, lane, recL);                          // L = chol(S,'L')
         if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
         if (ok) {
-          // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0,
-          // A (U is dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the ballots ignore NaN
-          for (int j = 0; j < P; ++j)
-            if (lane < P) {
-              const double l = L_(S, lane, j), r = 1.0 / l;
-              const double nan = __builtin_nan("");
-              L_(Ri, lane, j) = (l > 0.0 && lane < P - 1) ? r : nan;
-              L_(A, lane, j) = (l < 0.0 && lane < P - 1) ? r : nan;
-            }
           double z = lane < P ? a.beta_prev[lane] - m : 0.0;                 // z = L^{-1}(beta_prev - mP)
           z = w_solve_L_vec(S, z, P, ld, lane);
           if (lane < P) zz[lane] = z;
@@ -1593,6 +1584,16 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   }
   if (mode != blk::B_CONSTRAINED) return;
 
+  // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0, A (U is
+  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3, while
+  // wave 0 applies the swaps below.
+  for (int e = t - 64; e >= 0 && e < P * P; e += kBlock - 64) {
+    const int i = e % P, j = e / P;
+    const double l = L_(S, i, j), r = 1.0 / l;
+    const double nan = __builtin_nan("");
+    L_(Ri, i, j) = (l > 0.0 && i < P - 1) ? r : nan;
+    L_(A, i, j) = (l < 0.0 && i < P - 1) ? r : nan;
+  }
   // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel (thread k,
   // its row of ptab in LDS as scratch), then composed in scan order: `is` persists across scans
   // (Logit.hpp:368-377); the composition is in place, row by row.
