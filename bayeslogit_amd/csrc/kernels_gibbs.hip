@@ -1465,7 +1465,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   int* ptab = perm + P + (P & 1);                    // ptab[k][i]: coordinate visited at step i of scan k (P*P ints)
   double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
-  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);   // P*(P-1) swap targets
   __shared__ int bad;
   if (t == 0) bad = 0;
   if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
@@ -1547,34 +1546,59 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   } else if (mode == blk::B_CONSTRAINED) {
     // ====== waves 1-3, meanwhile: every random input of the draw, in stream order
     // (per scan k, P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms) ======
-    const int tt = t - 64, nt = kBlock - 64;
+    const int tt = t - 64;
     const uint32_t per_scan = (uint32_t)(10 * P - 1);
-    for (int e = tt; e < P * (P - 1); e += nt) {
-      const int k = e / (P - 1), i = e % (P - 1);
-      const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
-      swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P), Logit.hpp:375
-    }
-    for (int e = tt; e < P * P; e += nt) {
-      const int k = e / P, i = e % P;
-      const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
-      double* R = rec + (size_t)e * kRec;
-      for (int m = 0; m < 4; ++m) {
-        const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
-        const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
-        const double lua = log(ua);
-        R[4 * m] = ua;
-        R[4 * m + 1] = lua;
-        R[4 * m + 2] = log(ub);
-        R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+    // the tnorm records: waves 2-3 take the first 25/32 of them, wave 1 the rest once the scan tables are built
+    const int nsplit = (P * P * 25) / 32;
+    auto records = [&](int e0, int e1, int first, int stride) {
+      for (int e = e0 + first; e < e1; e += stride) {
+        const int k = e / P, i = e % P;
+        const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+        double* R = rec + (size_t)e * kRec;
+        for (int m = 0; m < 4; ++m) {
+          const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+          const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+          const double lua = log(ua);
+          R[4 * m] = ua;
+          R[4 * m + 1] = lua;
+          R[4 * m + 2] = log(ub);
+          R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+        }
+        R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+        R[17] = R[18] = R[19] = 0.0;
       }
-      R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
-      R[17] = R[18] = R[19] = 0.0;
+    };
+    if (tt < 64) {
+      // wave 1: the scan tables.  Scan k's P-1 swaps (r.flat(i, P), Logit.hpp:375-377) applied to the identity,
+      // all scans in parallel (lane k, its row of ptab as scratch), then composed in scan order: `is` persists
+      // across scans (Logit.hpp:368-377); the composition is in place, row by row.  One wavefront: no
+      // workgroup barrier, wave 0 is in the dense stage.
+      if (tt < P) {
+        int* sg = ptab + tt * P;
+        for (int i = 0; i < P; ++i) sg[i] = i;
+        for (int i = 0; i < P - 1; ++i) {
+          const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)tt * per_scan + (uint32_t)i);
+          const int j = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P)
+          const int tmp = sg[i];
+          sg[i] = sg[j];
+          sg[j] = tmp;
+        }
+      }
+      WAVE_SYNC();
+      for (int k = 1; k < P; ++k) {
+        int v = 0;
+        if (tt < P) v = ptab[(k - 1) * P + ptab[k * P + tt]];
+        WAVE_SYNC();
+        if (tt < P) ptab[k * P + tt] = v;
+        WAVE_SYNC();
+      }
+      records(nsplit, P * P, tt, 64);
+    } else {
+      records(0, nsplit, tt - 64, kBlock - 128);
     }
-    // swap targets are read back by wave 1 only: make its own and its neighbours' stores visible
+    // the records are read back (staged into LDS) by every wave after the barrier below
     __threadfence_block();
     if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
-    // named barrier among waves 1-3 is not available: scan permutations are built after the
-    // workgroup barrier below instead (they are cheap: LDS only)
   }
   if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
   __syncthreads();
@@ -1585,8 +1609,8 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (mode != blk::B_CONSTRAINED) return;
 
   // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0, A (U is
-  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3, while
-  // wave 0 applies the swaps below.
+  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3 (wave 0
+  // has just left the dense stage).
   for (int e = t - 64; e >= 0 && e < P * P; e += kBlock - 64) {
     const int i = e % P, j = e / P;
     const double l = L_(S, i, j), r = 1.0 / l;
@@ -1594,27 +1618,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     L_(Ri, i, j) = (l > 0.0 && i < P - 1) ? r : nan;
     L_(A, i, j) = (l < 0.0 && i < P - 1) ? r : nan;
   }
-  // scan k's P-1 swaps (Logit.hpp:375-377) applied to the identity, all scans in parallel (thread k,
-  // its row of ptab in LDS as scratch), then composed in scan order: `is` persists across scans
-  // (Logit.hpp:368-377); the composition is in place, row by row.
-  if (t < P) {
-    int* sg = ptab + t * P;
-    for (int i = 0; i < P; ++i) sg[i] = i;
-    for (int i = 0; i < P - 1; ++i) {
-      const int j = swp[t * (P - 1) + i];
-      const int tmp = sg[i];
-      sg[i] = sg[j];
-      sg[j] = tmp;
-    }
-  }
-  __syncthreads();
-  for (int k = 1; k < P; ++k) {
-    int v = 0;
-    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
-    __syncthreads();
-    if (t < P) ptab[k * P + t] = v;
-    __syncthreads();
-  }
+  __syncthreads();                                 // 1/L complete
 
   if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
   if (a.dbg && t == 0) a.dbg[9] = clock64();
