@@ -1466,7 +1466,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
   __shared__ int bad;
+  __shared__ int uflag;                              // 0: U not ready; 1: U = chol(PP) is in A; 2: PP not positive definite
   if (t == 0) bad = 0;
+  if (t == 0) uflag = 0;
   if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
   const bool need_inverse = mode == blk::B_CONSTRAINED || mode == blk::B_FROM_LIK;
   for (int e = t; e < P * P; e += kBlock) {
@@ -1507,6 +1509,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     // ================= wave 0: the dense stage, alone, no workgroup barriers =================
     const int lane = t;
     bool ok = w_chol_reg<false>(A, P, ld, lane, recL);                        // U = chol(PP,'U') (recL is idle until the sweeps)
+    // wave 1 solves for mP from U once its own work is done (it idles otherwise): hand U over
+    __threadfence_block();
+    if (lane == 0) __hip_atomic_store(&uflag, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
     if (ok && need_inverse) {
       w_inverse_from_U(A, S, P, ld, lane);                                     // S = PP^{-1}
@@ -1528,18 +1533,10 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           a.beta_out[lane] = le + mean;
         }
       } else {
-        // B_CONSTRAINED set-up, Logit.hpp:335-366
-        double m = lane < P ? a.bP[lane] : 0.0;
-        m = w_solve_Ut_vec(A, m, P, ld, lane);
-        m = w_solve_U_vec(A, m, P, ld, lane);                                 // mP
+        // B_CONSTRAINED set-up, Logit.hpp:335-366 (mP: wave 1; z: after the barrier, when mP is there)
         if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
         ok = w_chol_reg<true>(S, P, ld, lane, recL);                          // L = chol(S,'L')
         if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
-        if (ok) {
-          double z = lane < P ? a.beta_prev[lane] - m : 0.0;                 // z = L^{-1}(beta_prev - mP)
-          z = w_solve_L_vec(S, z, P, ld, lane);
-          if (lane < P) zz[lane] = z;
-        }
       }
     }
     if (!ok && t == 0) bad = 1;
@@ -1593,6 +1590,18 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         WAVE_SYNC();
       }
       records(nsplit, P * P, tt, 64);
+      // mP = U^{-1} U^{-T} bP (Logit.hpp:335-340), as soon as wave 0 has published U (long since, normally)
+      int f;
+      do {
+        f = __hip_atomic_load(&uflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!f) __builtin_amdgcn_s_sleep(8);
+      } while (!f);
+      if (f == 1) {
+        double m = tt < P ? a.bP[tt] : 0.0;
+        m = w_solve_Ut_vec(A, m, P, ld, tt);
+        m = w_solve_U_vec(A, m, P, ld, tt);
+        if (tt < P) mP[tt] = m;
+      }
     } else {
       records(0, nsplit, tt - 64, kBlock - 128);
     }
@@ -1609,14 +1618,19 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (mode != blk::B_CONSTRAINED) return;
 
   // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0, A (U is
-  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3 (wave 0
-  // has just left the dense stage).
+  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3; wave 0
+  // solves for z meanwhile.
   for (int e = t - 64; e >= 0 && e < P * P; e += kBlock - 64) {
     const int i = e % P, j = e / P;
     const double l = L_(S, i, j), r = 1.0 / l;
     const double nan = __builtin_nan("");
     L_(Ri, i, j) = (l > 0.0 && i < P - 1) ? r : nan;
     L_(A, i, j) = (l < 0.0 && i < P - 1) ? r : nan;
+  }
+  if (t < 64) {
+    double z = t < P ? a.beta_prev[t] - mP[t] : 0.0;                         // z = L^{-1}(beta_prev - mP)
+    z = w_solve_L_vec(S, z, P, ld, t);
+    if (t < P) zz[t] = z;
   }
   __syncthreads();                                 // 1/L complete
 
