@@ -984,8 +984,9 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
 //     because a tnorm call owns exactly nine uniforms whatever its bounds): the P-1 swap
 //     targets of each random scan and, per tnorm call, the four proposal pairs with their
 //     logs and Box-Muller normal already taken;
-//   * lane j of one wavefront owns row j (beta_j, z_j in registers); the bounds of a move are
-//     a 64-lane max/min by DPP (no LDS round trip), with 1/L precomputed elementwise.
+//   * lane j of a wavefront owns row j (beta_j in a register, z in LDS); the moves are taken in speculative
+//     groups on all four wavefronts (see the kernel), and a move that needs its bounds gets them as a 64-lane
+//     max/min by DPP (no LDS round trip), with 1/L precomputed elementwise.
 #define L_(M, i, j) ((M)[(i) + (j) * ld])
 
 template <int CTRL>
@@ -1201,8 +1202,8 @@ constexpr int kRec = 20;   // doubles per pre-generated tnorm record: 4 attempts
 // One wave needs no s_barrier: LDS operations of a wave execute in program order, so a
 // wave-level scheduling fence between a phase's writes and the next phase's reads is enough.
 // The workgroup versions above pay two or three barriers per column (~1.4 us per column
-// measured); these run a 64x64 factorisation in ~15-20 us, and leave the other three waves free
-// to generate the draw's random input at the same time.
+// measured); these leave the other three waves free to generate the draw's random input, build the scan
+// tables and solve for mP at the same time.
 #define WAVE_SYNC()                                        \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
