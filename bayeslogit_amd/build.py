@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libbayeslogit_hip.so")
-SOURCES = ["host_state.hip", "kernels_pg.hip", "kernels_gibbs.hip", "capi_gibbs.hip", "combine.hip"]
+SOURCES = ["host_state.hip", "kernels_pg.hip", "kernels_tasks.hip", "kernels_gibbs.hip", "capi_gibbs.hip", "combine.hip"]
+# per-file flags (see the head of the file named)
+EXTRA = {"kernels_tasks.hip": ["-mllvm", "-disable-machine-licm"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -36,7 +38,7 @@ def _compile(src):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + _deps()):
-        subprocess.check_call([HIPCC] + FLAGS + ["-c", path, "-o", obj])
+        subprocess.check_call([HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj])
     return obj
 
 

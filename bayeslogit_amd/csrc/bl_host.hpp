@@ -17,6 +17,10 @@ bool ensure_device();                       // false => BL_ERR_NO_DEVICE recorde
 int* status_word(hipStream_t s);            // device int, zeroed per sync
 int  collect_status(hipStream_t s);         // sync + read + reset flags
 
+// kernels_tasks.hip: the alternating-series (sp == false) or saddle-point work-queue kernel over (h, z); x zeroed by the caller
+int launch_rpg_tasks(bool sp, double* x, const double* h, const double* z, int64_t num, int* iter, uint64_t seed,
+                     uint32_t epoch, uint64_t idx0, int hybrid, hipStream_t s);
+
 uint64_t global_seed();
 uint32_t next_epoch();                      // returns current, then increments
 int      global_constrain();

@@ -1,8 +1,7 @@
 // bl_pg_hybrid.hpp -- device dispatch of one PG(b, z) draw by shape, as the
 // reference's rpg_hybrid does (Code/C/LogitWrapper.cpp:140-162).  gfx950 only.
 #pragma once
-#include "bl_pg_alt.hpp"
-#include "bl_pg_sp.hpp"
+#include "bl_pg_devroye.hpp"
 #include "bl_pg1_sm.hpp"
 
 namespace bl {
@@ -20,8 +19,9 @@ __device__ __host__ __forceinline__ int pg_class(double b)
   return CLS_ZERO;
 }
 
-// One draw of class `cls` on the observation's stream.  CLS_DEVROYE (b = 1, 2) is not taken here: its
-// callers run pg1_draw_n (bl_pg1_sm.hpp), which owns the stream block by block.
+// One draw of class `cls` on the observation's stream, for the two classes drawn one observation per lane
+// (the normal approximation above b = 170, the sum of gammas below 1).  CLS_DEVROYE runs pg1_draw_n
+// (bl_pg1_sm.hpp); CLS_ALT and CLS_SP run as tasks under the work queue of bl_task_queue.hpp.
 __device__ inline double pg_hybrid_class(int cls, double b, double z, Stream& r, int& status)
 {
   double x = 0.0;
@@ -31,8 +31,6 @@ __device__ inline double pg_hybrid_class(int cls, double b, double z, Stream& r,
       const double v = pg_m2(b, z) - m * m;
       x = r.norm(m, sqrt(v));
     } break;
-    case CLS_SP: sp_draw(x, b, z, r, 200, status); break;
-    case CLS_ALT: x = alt_draw(b, z, r, status); break;
     case CLS_GAMMA: x = pg_draw_sum_of_gammas(b, z, 200, r); break;
     default: x = 0.0;
   }

@@ -13,6 +13,12 @@
 #define BL_HD inline
 #define BL_HD_COLD inline
 #endif
+// constant tables: device memory under hipcc (the kernels index them per lane), plain statics in the host harness
+#if defined(__HIPCC__)
+#define BL_DEVCONST __device__ const
+#else
+#define BL_DEVCONST static const
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BL_COSPI(x) cospi(x)
 #else

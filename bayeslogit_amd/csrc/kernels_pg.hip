@@ -110,47 +110,8 @@ __global__ __launch_bounds__(kBlock, CLS == 1 ? 3 : 2) void k_rpg_devroye(double
   if (st_flags) atomicOr(status, st_flags);
 }
 
-// ------------------------------------------------ rpg_alt / rpg_sp / rpg_gamma
-__global__ __launch_bounds__(kBlock, 3) void k_rpg_alt(double* __restrict__ x, const double* __restrict__ h,
-                                                    const double* __restrict__ z, int64_t num, uint64_t seed,
-                                                    uint32_t epoch, uint64_t idx0, int* __restrict__ status)
-{
-  int st = 0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
-    double out = 0.0;
-    if (h[i] != 0.0) {
-      Stream r;
-      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
-      out = alt_draw(h[i], z[i], r, st);
-    }
-    x[i] = out;
-  }
-  if (st) atomicOr(status, st);
-}
-
-__global__ __launch_bounds__(kBlock, 3) void k_rpg_sp(double* __restrict__ x, const double* __restrict__ h,
-                                                   const double* __restrict__ z, int64_t num,
-                                                   int* __restrict__ iter, uint64_t seed, uint32_t epoch,
-                                                   uint64_t idx0, int* __restrict__ status)
-{
-  int st = 0;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < num; i += stride) {
-    if (h[i] != 0.0) {
-      Stream r;
-      r.init(seed, idx0 + (uint64_t)i, DOM_DRAW, epoch);
-      double out;
-      const int it = sp_draw(out, h[i], z[i], r, 200, st);
-      x[i] = out;
-      if (iter) iter[i] = it;
-    } else {
-      x[i] = 0.0;   // iter[i] untouched, LogitWrapper.cpp:118-121
-    }
-  }
-  if (st) atomicOr(status, st);
-}
-
+// ------------------------------------------------------------------ rpg_gamma
+// (rpg_alt and rpg_sp: k_rpg_tasks<AltPolicy> / <SpPolicy>, bl_task_queue.hpp)
 __global__ __launch_bounds__(kBlock) void k_rpg_gamma(double* __restrict__ x, const double* __restrict__ h,
                                                       const double* __restrict__ z, int64_t num, int trunc,
                                                       uint64_t seed, uint32_t epoch, uint64_t idx0)
@@ -168,31 +129,18 @@ __global__ __launch_bounds__(kBlock) void k_rpg_gamma(double* __restrict__ x, co
 }
 
 // ----------------------------------------------------------------- rpg_hybrid
-// The five branches of LogitWrapper.cpp:142-161 have very different register
-// footprints and trip counts; a lane-per-observation kernel that switches per
-// lane would keep the union of all branches' registers live and serialise every
-// branch in every wavefront.  The launch is therefore split by class: each pass
-// is a separate kernel instantiation that contains the code of ONE class only
-// and skips observations of the other classes.  Streams are per observation, so
-// the result is identical to the unsplit loop.
-// Inside a pass the observations of the class are scattered (4 % / 22 % / 74 % of a C3 vector), and
-// their cost differs (an Alt draw is 1..4 abridged draws).  A wave therefore scans chunks of kChunkH
-// observations, COMPACTS the members of its class into an LDS index list (ballot + prefix popcount),
-// bucketed by a cost key, and then draws them 64 at a time: every lane of a batch is busy and the
-// lanes of a batch do about the same amount of work.
+// The five branches of LogitWrapper.cpp:142-161 have very different register footprints and trip
+// counts; a lane-per-observation kernel that switches per lane would keep the union of all branches'
+// registers live and serialise every branch in every wavefront.  The launch is therefore split by class:
+// each pass is a separate kernel that contains the code of ONE class only and skips the observations
+// of the others.  Streams are per observation, so the result is identical to the unsplit loop.
+//   b > 13  saddle point          k_rpg_tasks<SpPolicy>   (bl_task_queue.hpp)
+//   b > 1   alternating series    k_rpg_tasks<AltPolicy>
+//   b = 1,2 Devroye; b > 170 normal approximation; 0 < b < 1 sum of gammas: k_rpg_hybrid_class below --
+//           the class's observations (scattered in the vector) COMPACTED per 4096-observation chunk into an
+//           LDS index list (ballot + prefix popcount; Devroye: b = 1 before b = 2) and drawn 64 at a time.
+//   b <= 0  0: the zeroing launch in front of the passes.
 constexpr int kChunkH = 4096;
-
-template <int CLS>
-__device__ __forceinline__ int pg_cost_key(double b)
-{
-  if (CLS == CLS_ALT) {                       // number of abridged draws, PolyaGammaAlt.cpp:205-225
-    const double n = floor((b - 1.0) / 4.0);
-    const int nd = (int)n + ((b - 4.0 * n) > 4.0 ? 2 : 1);
-    return nd >= 4 ? 3 : nd - 1;
-  }
-  if (CLS == CLS_DEVROYE) return b == 2.0 ? 1 : 0;
-  return 0;
-}
 
 template <int CLS>
 __global__ __launch_bounds__(kBlock, 3) void k_rpg_hybrid_class(double* __restrict__ x,
@@ -201,7 +149,8 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_hybrid_class(double* __restri
                                                              uint64_t seed, uint32_t epoch, uint64_t idx0,
                                                              int* __restrict__ status)
 {
-  constexpr int NKEY = CLS == CLS_ALT ? 4 : CLS == CLS_DEVROYE ? 2 : 1;
+  static_assert(CLS == CLS_DEVROYE || CLS == CLS_NORMAL || CLS == CLS_GAMMA, "the other classes run as tasks");
+  constexpr int NKEY = CLS == CLS_DEVROYE ? 2 : 1;      // Devroye: one draw (b = 1) or two (b = 2)
   __shared__ unsigned short sIdx[kBlock / 64][kChunkH];
   __shared__ unsigned char sKey[kBlock / 64][NKEY > 1 ? kChunkH : 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -228,11 +177,7 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_hybrid_class(double* __restri
       for (int j = 0; j < 8; ++j) {
         const int k = (j0 + j) * 64 + lane;
         const bool mine = k < cnt && pg_class(hk[j]) == CLS;
-        if (CLS == CLS_ZERO) {
-          if (mine) x[base + k] = 0.0;
-          continue;
-        }
-        const int key = mine ? pg_cost_key<CLS>(hk[j]) : NKEY;
+        const int key = mine ? (CLS == CLS_DEVROYE && hk[j] == 2.0 ? 1 : 0) : NKEY;
         if (NKEY > 1) {
           if (k < cnt) sKey[wave][k] = (unsigned char)key;
 #pragma unroll
@@ -244,7 +189,6 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_hybrid_class(double* __restri
         }
       }
     }
-    if (CLS == CLS_ZERO) continue;
     int total = nkey[0];
     if (NKEY > 1) {
       // pass B: fill the list, bucket after bucket
@@ -391,32 +335,6 @@ int bl_rpg_devroye_dev(double* x, const int* n_vec, int n_scalar, const double* 
   return BL_OK;
 }
 
-int bl_rpg_alt_dev(double* x, const double* h, const double* z, int64_t num, uint64_t seed, uint32_t epoch,
-                   uint64_t idx0, void* stream)
-{
-  if (int rc = check_args(x, z, num)) return rc;
-  if (num == 0) return BL_OK;
-  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rpg_alt, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, h, z, num, seed,
-                     epoch, idx0, blh::status_word(s));
-  BL_HIP_TRY(hipGetLastError());
-  return BL_OK;
-}
-
-int bl_rpg_sp_dev(double* x, const double* h, const double* z, int64_t num, int* iter, uint64_t seed,
-                  uint32_t epoch, uint64_t idx0, void* stream)
-{
-  if (int rc = check_args(x, z, num)) return rc;
-  if (num == 0) return BL_OK;
-  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rpg_sp, dim3(blh::grid_for(num, kBlock, kMaxBlocks)), dim3(kBlock), 0, s, x, h, z, num, iter,
-                     seed, epoch, idx0, blh::status_word(s));
-  BL_HIP_TRY(hipGetLastError());
-  return BL_OK;
-}
-
 int bl_rpg_gamma_dev(double* x, const double* h, const double* z, int64_t num, int trunc, uint64_t seed,
                      uint32_t epoch, uint64_t idx0, void* stream)
 {
@@ -439,11 +357,12 @@ int bl_rpg_hybrid_dev(double* x, const double* h, const double* z, int64_t num, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(blh::grid_for(num, kBlock, kMaxBlocks)), b(kBlock);
   int* st = blh::status_word(s);
-  // Every class pass is launched; a pass whose class is absent costs one read of h.
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_ZERO>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  // Every class pass is launched; a pass whose class is absent costs one read of h.  x is zeroed first: that is
+  // the b <= 0 branch (LogitWrapper.cpp:159-161), and the alternating-series tasks add their sums into it.
+  BL_HIP_TRY(hipMemsetAsync(x, 0, sizeof(double) * (size_t)num, s));
+  if (int rc = blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, 1, s)) return rc;    // saddle point
+  if (int rc = blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, 1, s)) return rc;   // alternating series
   hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_ALT>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_SP>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
   hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
   hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
   BL_HIP_TRY(hipGetLastError());

@@ -76,6 +76,7 @@ double bl_pg_draw_like_devroye(double z, bl_rng *r);           /* attempt form (
 double bl_pg_draw_devroye(int n, double z, bl_rng *r);
 double bl_pg_draw_like_devroye_literal(double z, bl_rng *r);   /* the reference loops, literally */
 double bl_pg_draw_devroye_literal(int n, double z, bl_rng *r);
+void   bl_pg_devroye_literal_census(double Z, int64_t ndraws, uint64_t seed, int64_t counts[4], int64_t *nprop);
 double bl_pg_draw_sum_of_gammas(double b, double z, int trunc, bl_rng *r);
 double bl_pg_m1(double b, double z);
 double bl_pg_m2(double b, double z);
@@ -101,6 +102,20 @@ int    bl_sp_draw(double *d, double n, double z, bl_rng *r, int maxiter);
 
 double bl_pg_hybrid(double b, double z, bl_rng *r);
 
+/* ---- the Alt and SP samplers in the attempt form the HIP kernels execute (pg_attempt.c) ---- */
+typedef struct { double h, Z, t, fz, p, ip, iq, R, b, ic0, omc, log_m, cR; int small; } bl_alt_par;
+void   bl_alt_par_of(bl_alt_par *p, double h, double z);
+int    bl_alt_attempt(int *state, double *X, const bl_alt_par *p, double u1, double u2);
+double bl_alt_draw_attempt(double h, double z, bl_rng *r);
+typedef struct { double n, Z2, md, logmd, lcZ, lhal, lhar, rl, il, rr, ir, mu, pl, ipl, iql, b, ic0, omc, log_m; } bl_sp_par;
+extern const double bl_vtab[3][16][11];
+void   bl_sp_vlk(double x, double logx, double *v, double *L, double *lK2);
+void   bl_sp_par_of(bl_sp_par *p, double n, double z);
+int    bl_sp_attempt(int *state, double *X, int *accepted, const bl_sp_par *p, double u1, double u2);
+int    bl_sp_draw_attempt(double *d, double n, double z, bl_rng *r, int maxiter);
+double bl_upper_gamma_cf(double a, double x);
+double bl_pg_hybrid_attempt(double b, double z, bl_rng *r);
+
 /* ---- vector entry points mirroring Code/C/LogitWrapper.h:23-64, plus the
  *      (seed, epoch, index offset) of the counter stream ---- */
 void bl_o_rpg_devroye(double *x, const int *n, const double *z, int64_t num,
@@ -113,6 +128,14 @@ void bl_o_rpg_gamma  (double *x, const double *h, const double *z, int64_t num, 
                       uint64_t seed, uint32_t epoch, uint64_t idx0);
 void bl_o_rpg_hybrid (double *x, const double *h, const double *z, int64_t num,
                       uint64_t seed, uint32_t epoch, uint64_t idx0);
+/* the same three on the attempt forms (what the HIP path computes, draw for draw); nblk (may be
+ * NULL) receives the number of Philox blocks each observation consumed */
+void bl_o_rpg_alt_attempt   (double *x, const double *h, const double *z, int64_t num,
+                             uint64_t seed, uint32_t epoch, uint64_t idx0, uint32_t *nblk);
+void bl_o_rpg_sp_attempt    (double *x, const double *h, const double *z, int64_t num, int *iter,
+                             uint64_t seed, uint32_t epoch, uint64_t idx0, uint32_t *nblk);
+void bl_o_rpg_hybrid_attempt(double *x, const double *h, const double *z, int64_t num,
+                             uint64_t seed, uint32_t epoch, uint64_t idx0);
 /* OpenMP variant of the hybrid loop, one stream per observation, schedule(dynamic)
  * as Code/C/PolyaGammaOMP.h:61-71 (timed CPU baseline on all host cores). */
 void bl_o_rpg_hybrid_omp(double *x, const double *h, const double *z, int64_t num,

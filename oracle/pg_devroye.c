@@ -115,6 +115,35 @@ double bl_pg_draw_like_devroye_literal(double Z, bl_rng *r)
   }
 }
 
+/* Census of the literal loop above: counts[j] (j = 1..3) = number of proposals whose series test ended
+ * at term j (counts[0]: later terms), *nprop = proposals made, over ndraws draws.  The reference's notes
+ * state these frequencies analytically (Notes/notes.tex:1000-1027); tests/test_oracle_pins.py compares. */
+void bl_pg_devroye_literal_census(double Z, int64_t ndraws, uint64_t seed, int64_t counts[4], int64_t *nprop)
+{
+  Z = fabs(Z) * 0.5;
+  double fz = 0.125 * PG_PI * PG_PI + 0.5 * Z * Z;
+  double mass = bl_pg_mass_texpon(Z);
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  *nprop = 0;
+  for (int64_t i = 0; i < ndraws; ++i) {
+    bl_rng rr, *r = &rr;
+    bl_rng_init(r, seed, (uint64_t)i, BL_DOM_DRAW, 0);
+    int accepted = 0;
+    while (!accepted) {
+      double X = bl_unif(r) < mass ? PG_TRUNC + bl_expon_rate(r, 1) / fz : bl_pg_rtigauss(Z, r);
+      double S = bl_pg_a(0, X);
+      double Y = bl_unif(r) * S;
+      *nprop += 1;
+      for (int n = 1;; ++n) {
+        int stop;
+        if (n % 2 == 1) { S = S - bl_pg_a(n, X); stop = Y <= S; accepted = stop; }
+        else            { S = S + bl_pg_a(n, X); stop = Y > S; }
+        if (stop) { counts[n <= 3 ? n : 0] += 1; break; }
+      }
+    }
+  }
+}
+
 /* ---- the attempt form (one Philox block = two uniforms per proposal attempt) ----
  * Same events as the literal loops above:
  *   right piece (u1 < mass, PolyaGamma.cpp:170-171): E = -log(u1/mass), X = t + E/fz;

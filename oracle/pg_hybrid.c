@@ -108,6 +108,45 @@ void bl_o_rpg_hybrid(double *x, const double *h, const double *z, int64_t num,
   }
 }
 
+/* the attempt forms of pg_attempt.c, observation by observation on the same streams */
+void bl_o_rpg_alt_attempt(double *x, const double *h, const double *z, int64_t num,
+                          uint64_t seed, uint32_t epoch, uint64_t idx0, uint32_t *nblk)
+{
+  for (int64_t i = 0; i < num; ++i) {
+    bl_rng r;
+    bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_DRAW, epoch);
+    x[i] = (h[i] != 0) ? bl_alt_draw_attempt(h[i], z[i], &r) : 0.0;
+    if (nblk) nblk[i] = (uint32_t)(r.nunif / 2);
+  }
+}
+
+void bl_o_rpg_sp_attempt(double *x, const double *h, const double *z, int64_t num, int *iter,
+                         uint64_t seed, uint32_t epoch, uint64_t idx0, uint32_t *nblk)
+{
+  for (int64_t i = 0; i < num; ++i) {
+    bl_rng r;
+    bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_DRAW, epoch);
+    if (h[i] != 0) {
+      int it = bl_sp_draw_attempt(&x[i], h[i], z[i], &r, 200);
+      if (iter) iter[i] = it;
+    } else {
+      x[i] = 0.0;
+    }
+    if (nblk) nblk[i] = (uint32_t)(r.nunif / 2);
+  }
+}
+
+void bl_o_rpg_hybrid_attempt(double *x, const double *h, const double *z, int64_t num,
+                             uint64_t seed, uint32_t epoch, uint64_t idx0)
+{
+  #pragma omp parallel for schedule(dynamic, 4096)
+  for (int64_t i = 0; i < num; ++i) {
+    bl_rng r;
+    bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_DRAW, epoch);
+    x[i] = bl_pg_hybrid_attempt(h[i], z[i], &r);
+  }
+}
+
 void bl_o_rpg_hybrid_omp(double *x, const double *h, const double *z, int64_t num,
                          uint64_t seed, uint32_t epoch, uint64_t idx0, int nthreads)
 {

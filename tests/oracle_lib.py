@@ -79,6 +79,13 @@ def lib():
     sig("bl_o_rpg_sp", None, c_dp, c_dp, c_dp, c_i64, c_ip, c_u64, c_u32, c_u64)
     sig("bl_o_rpg_gamma", None, c_dp, c_dp, c_dp, c_i64, C.c_int, c_u64, c_u32, c_u64)
     sig("bl_o_rpg_hybrid", None, c_dp, c_dp, c_dp, c_i64, c_u64, c_u32, c_u64)
+    c_u32p = C.POINTER(c_u32)
+    sig("bl_o_rpg_alt_attempt", None, c_dp, c_dp, c_dp, c_i64, c_u64, c_u32, c_u64, c_u32p)
+    sig("bl_o_rpg_sp_attempt", None, c_dp, c_dp, c_dp, c_i64, c_ip, c_u64, c_u32, c_u64, c_u32p)
+    sig("bl_o_rpg_hybrid_attempt", None, c_dp, c_dp, c_dp, c_i64, c_u64, c_u32, c_u64)
+    sig("bl_pg_devroye_literal_census", None, c_d, c_i64, c_u64, C.POINTER(c_i64), C.POINTER(c_i64))
+    sig("bl_sp_vlk", None, c_d, c_d, c_dp, c_dp, c_dp)
+    sig("bl_upper_gamma_cf", c_d, c_d, c_d)
     sig("bl_o_rpg_hybrid_omp", None, c_dp, c_dp, c_dp, c_i64, c_u64, c_u32, c_u64, C.c_int)
     sig("bl_o_max_threads", C.c_int)
     sig("bl_o_gibbs", C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_i64, C.c_int,
@@ -147,11 +154,24 @@ def _rpg_h(fn, num, h, z, seed, epoch, idx0, *extra):
     return x
 
 
-def rpg_alt(num, h, z, seed, epoch=0, idx0=0):
-    return _rpg_h(lib().bl_o_rpg_alt, num, h, z, seed, epoch, idx0)
+def rpg_alt(num, h, z, seed, epoch=0, idx0=0, literal=False, blocks=False):
+    """literal=False: the attempt form (what the HIP path computes, draw for draw);
+    literal=True: PolyaGammaAlt.cpp's loops call for call (same distribution, other stream use)."""
+    if literal:
+        return _rpg_h(lib().bl_o_rpg_alt, num, h, z, seed, epoch, idx0)
+    h = _f64(h, num)
+    z = _f64(z, num)
+    x = np.zeros(num)
+    nb = np.zeros(num, dtype=np.uint32)
+    lib().bl_o_rpg_alt_attempt(dp(x), dp(h), dp(z), num, seed, epoch, idx0, nb.ctypes.data_as(C.POINTER(c_u32)))
+    return (x, nb) if blocks else x
 
 
-def rpg_hybrid(num, h, z, seed, epoch=0, idx0=0, threads=0):
+def rpg_hybrid(num, h, z, seed, epoch=0, idx0=0, threads=0, literal=False):
+    """literal=False: every branch in the form the HIP path computes; literal=True: Alt and SP by the
+    reference's loops (Devroye stays in its attempt form; rpg_devroye(literal=True) has the loops)."""
+    if not literal:
+        return _rpg_h(lib().bl_o_rpg_hybrid_attempt, num, h, z, seed, epoch, idx0)   # OpenMP inside: same draws
     if threads:
         h = _f64(h, num)
         z = _f64(z, num)
@@ -165,13 +185,30 @@ def rpg_gamma(num, h, z, seed, trunc=200, epoch=0, idx0=0):
     return _rpg_h(lib().bl_o_rpg_gamma, num, h, z, seed, epoch, idx0, trunc)
 
 
-def rpg_sp(num, h, z, seed, epoch=0, idx0=0):
+def rpg_sp(num, h, z, seed, epoch=0, idx0=0, literal=False, blocks=False):
     h = _f64(h, num)
     z = _f64(z, num)
     x = np.zeros(num)
     it = np.zeros(num, dtype=np.int32)
-    lib().bl_o_rpg_sp(dp(x), dp(h), dp(z), num, ip(it), seed, epoch, idx0)
-    return x, it
+    if literal:
+        lib().bl_o_rpg_sp(dp(x), dp(h), dp(z), num, ip(it), seed, epoch, idx0)
+        return x, it
+    nb = np.zeros(num, dtype=np.uint32)
+    lib().bl_o_rpg_sp_attempt(dp(x), dp(h), dp(z), num, ip(it), seed, epoch, idx0, nb.ctypes.data_as(C.POINTER(c_u32)))
+    return (x, it, nb) if blocks else (x, it)
+
+
+def devroye_census(z, ndraws, seed):
+    counts = (c_i64 * 4)()
+    nprop = c_i64(0)
+    lib().bl_pg_devroye_literal_census(z, ndraws, seed, counts, C.byref(nprop))
+    return list(counts), nprop.value
+
+
+def sp_vlk(x):
+    v, L, k = c_d(), c_d(), c_d()
+    lib().bl_sp_vlk(x, float(np.log(x)), C.byref(v), C.byref(L), C.byref(k))
+    return v.value, L.value, k.value
 
 
 def gibbs(y, X, n, m0, P0, samp, burn, seed, constrain=1, store_w=True, idx0=0):

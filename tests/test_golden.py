@@ -1,4 +1,4 @@
-"""The committed golden vectors (tests/golden/pg_golden_v1.json, made by make_golden.py from the oracle)
+"""The committed golden vectors (tests/golden/pg_golden_v2.json, made by make_golden.py from the oracle)
 are reproduced bit-for-bit by the oracle.  The HIP path is checked against the same file under -m gpu."""
 import ctypes as C
 import json
@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def load():
-    return json.load(open(os.path.join(HERE, "golden", "pg_golden_v1.json")))
+    return json.load(open(os.path.join(HERE, "golden", "pg_golden_v2.json")))
 
 
 def test_oracle_reproduces_golden(oracle):
@@ -28,13 +28,19 @@ def test_oracle_reproduces_golden(oracle):
     for x, n, z, v in g["helpers"]["sp_approx"]:
         assert L.bl_sp_approx(x, n, z) == v
     for d in g["hybrid_draws"]:
-        x = oracle.rpg_hybrid(len(d["x"]), d["b"], d["z"], d["seed"], d["epoch"], d["idx0"])
-        assert x.tolist() == d["x"], d["b"]
+        for key, lit in (("x", False), ("x_literal", True)):
+            x = oracle.rpg_hybrid(len(d[key]), d["b"], d["z"], d["seed"], d["epoch"], d["idx0"], literal=lit)
+            assert x.tolist() == d[key], d["b"]
     d = g["devroye_n"]
     assert oracle.rpg_devroye(16, d["n"], np.array(d["z"]), d["seed"]).tolist() == d["x"]
     d = g["sp_iter"]
     xs, it = oracle.rpg_sp(6, d["h"], d["z"], d["seed"])
     assert xs.tolist() == d["x"] and it.tolist() == d["iter"]
+    xs, it = oracle.rpg_sp(6, d["h"], d["z"], d["seed"], literal=True)
+    assert xs.tolist() == d["x_literal"] and it.tolist() == d["iter_literal"]
+    d = g["alt"]
+    assert oracle.rpg_alt(10, d["h"], d["z"], d["seed"]).tolist() == d["x"]
+    assert oracle.rpg_alt(10, d["h"], d["z"], d["seed"], literal=True).tolist() == d["x_literal"]
 
 
 def test_oracle_reproduces_golden_gibbs(oracle):

@@ -117,7 +117,7 @@ def test_device_entry_points_match_oracle(gpu, oracle, case):
 
 def test_golden_vectors_on_gpu(gpu):
     from bayeslogit_amd import device as D
-    g = json.load(open(os.path.join(HERE, "golden", "pg_golden_v1.json")))
+    g = json.load(open(os.path.join(HERE, "golden", "pg_golden_v2.json")))
     for d in g["hybrid_draws"]:
         k = len(d["x"])
         h = torch.full((k,), d["b"], dtype=torch.float64, device=gpu)
@@ -135,6 +135,10 @@ def test_golden_vectors_on_gpu(gpu):
     D.sync_status()
     agree(x.cpu().numpy(), np.array(d["x"]))
     assert it.cpu().tolist() == d["iter"]
+    d = g["alt"]
+    x = D.rpg_alt(dev_t(d["h"], gpu), torch.full((10,), d["z"], dtype=torch.float64, device=gpu), seed=d["seed"])
+    D.sync_status()
+    agree(x.cpu().numpy(), np.array(d["x"]))
 
 
 def test_edge_cases(gpu, oracle):

@@ -89,11 +89,13 @@ MOMENT_GRID = [(1, 0.0), (1, 2.0), (2, 1.0), (2, 6.0), (1.01, 0.7), (3.0, 0.0), 
                (50.0, 2.0), (100.0, 5.0), (170.0, 0.1), (171.0, 1.0), (400.0, 3.0), (0.5, 1.0), (0.1, 0.0)]
 
 
+@pytest.mark.parametrize("literal", [True, False])
 @pytest.mark.parametrize("b,z", MOMENT_GRID)
-def test_hybrid_sample_moments(oracle, b, z):
-    """The reference's own criterion: sample m1, m2 next to pg_m1, pg_m2 (test_hybrid_par.cpp:55-59)."""
+def test_hybrid_sample_moments(oracle, b, z, literal):
+    """The reference's own criterion: sample m1, m2 next to pg_m1, pg_m2 (test_hybrid_par.cpp:55-59), for the
+    reference's loops (literal) and for the attempt forms the HIP path computes."""
     n = 3000 if b < 1 else 60000
-    x = oracle.rpg_hybrid(n, b, z, seed=int(b * 1000 + z * 10) + 7)
+    x = oracle.rpg_hybrid(n, b, z, seed=int(b * 1000 + z * 10) + 7, literal=literal)
     L = oracle.lib()
     m1, m2 = L.bl_pg_m1(b, z), L.bl_pg_m2(b, z)
     var = m2 - m1 * m1
@@ -108,17 +110,17 @@ def test_methods_agree_in_distribution(oracle):
     n = 20000
     z = 1.3
     d2 = oracle.rpg_devroye(n, 2, z, seed=1)
-    a2 = oracle.rpg_alt(n, 2.0, z, seed=2)
+    a2 = oracle.rpg_alt(n, 2.0, z, seed=2, literal=True)
     assert stats.ks_2samp(d2, a2).pvalue > 1e-3
     d1 = oracle.rpg_devroye(n, 1, z, seed=3)
-    a1 = oracle.rpg_alt(n, 1.0, z, seed=4)
+    a1 = oracle.rpg_alt(n, 1.0, z, seed=4, literal=True)
     assert stats.ks_2samp(d1, a1).pvalue > 1e-3
-    a14 = oracle.rpg_alt(n, 14.0, z, seed=5)
-    s14, it = oracle.rpg_sp(n, 14.0, z, seed=6)
+    a14 = oracle.rpg_alt(n, 14.0, z, seed=5, literal=True)
+    s14, it = oracle.rpg_sp(n, 14.0, z, seed=6, literal=True)
     assert stats.ks_2samp(a14, s14).pvalue > 1e-3
     assert it.min() >= 1 and it.max() <= 200 and it.mean() < 2.0
     g3 = oracle.rpg_gamma(4000, 3.0, z, seed=7)
-    a3 = oracle.rpg_alt(n, 3.0, z, seed=8)
+    a3 = oracle.rpg_alt(n, 3.0, z, seed=8, literal=True)
     assert stats.ks_2samp(g3, a3).pvalue > 1e-3
 
 
@@ -140,15 +142,18 @@ def test_inverty(oracle):
 def test_edge_cases(oracle):
     # n = 0 / h = 0 give 0 (LogitWrapper.cpp:74-77,95-98); n < 1 clamps to 1 in the NTHROW build
     assert oracle.rpg_devroye(3, [0, 0, 0], 1.0, 1).tolist() == [0, 0, 0]
-    assert oracle.rpg_alt(2, 0.0, 1.0, 1).tolist() == [0, 0]
-    assert oracle.rpg_hybrid(2, -1.0, 1.0, 1).tolist() == [0, 0]
-    assert oracle.rpg_alt(1, 0.5, 1.0, 1)[0] == 0.0                 # h < 1 -> 0, PolyaGammaAlt.cpp:207-210
+    for lit in (True, False):
+        assert oracle.rpg_alt(2, 0.0, 1.0, 1, literal=lit).tolist() == [0, 0]
+        assert oracle.rpg_hybrid(2, -1.0, 1.0, 1, literal=lit).tolist() == [0, 0]
+        assert oracle.rpg_alt(1, 0.5, 1.0, 1, literal=lit)[0] == 0.0   # h < 1 -> 0, PolyaGammaAlt.cpp:207-210
     # sign of z is irrelevant, per-observation streams make results order-independent
     a = oracle.rpg_devroye(100, 1, 2.5, seed=9)
     b = oracle.rpg_devroye(100, 1, -2.5, seed=9)
     assert np.array_equal(a, b)
-    full = oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4)
-    part = oracle.rpg_hybrid(400, 3.0, 1.0, seed=4, idx0=600)
-    assert np.array_equal(full[600:], part)
-    omp = oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4, threads=4)
-    assert np.array_equal(full, omp)
+    for lit in (True, False):
+        full = oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4, literal=lit)
+        part = oracle.rpg_hybrid(400, 3.0, 1.0, seed=4, idx0=600, literal=lit)
+        assert np.array_equal(full[600:], part)
+    omp = oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4, threads=4, literal=True)
+    assert np.array_equal(full, oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4)) and np.array_equal(
+        omp, oracle.rpg_hybrid(1000, 3.0, 1.0, seed=4, literal=True))

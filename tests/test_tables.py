@@ -33,10 +33,23 @@ def test_inverty_grid_identity():
     with np.errstate(invalid="ignore", divide="ignore"):
         yy = np.where(v > 0, np.tan(r) / r, np.where(v < 0, np.tanh(r) / r, 1.0))
     assert np.allclose(yy, y, rtol=5e-6)                                        # y = tan(sqrt v)/sqrt v
-    for path, ny, nv in ((os.path.join(ROOT, "oracle", "inverty_grid.c"), "bl_ygrid", "bl_vgrid"),
-                         (os.path.join(ROOT, "bayeslogit_amd", "csrc", "bl_tables.hpp"), "kYGrid", "kVGrid")):
-        assert np.array_equal(_c_table(path, ny), y)
-        assert np.array_equal(_c_table(path, nv), v)
+    path = os.path.join(ROOT, "oracle", "inverty_grid.c")
+    assert np.array_equal(_c_table(path, "bl_ygrid"), y)
+    assert np.array_equal(_c_table(path, "bl_vgrid"), v)
+
+
+def test_fitted_inversion_table_reproduces_reference_grid(oracle):
+    """The product's and the oracle's fitted table of v(x) (bl_vtab.hpp / oracle/vtab.c, scripts/gen_vtab.py)
+    passes through the reference's own (ygrid, vgrid) points (InvertY.hpp:20-57) to their 7 printed digits, and
+    the two copies hold the same numbers."""
+    g = np.loadtxt(os.path.join(HERE, "golden", "inverty_grid.txt"))
+    for k, (y, v) in enumerate(g):
+        vv, _, _ = oracle.sp_vlk(2.0 ** (-4 + 0.1 * k))      # the grid's exact abscissa (y is printed to 7 digits)
+        assert abs(vv - v) <= 6e-7 * max(1.0, abs(v)), (y, v, vv)
+    src = open(os.path.join(ROOT, "bayeslogit_amd", "csrc", "bl_vtab.hpp")).read()
+    osrc = open(os.path.join(ROOT, "oracle", "vtab.c")).read()
+    nums = lambda t: re.findall(r"-?\d\.\d+(?:e[-+]\d+)?|-?\d+\.\d+(?:e[-+]\d+)?", t[t.index("= {"):])
+    assert nums(src) == nums(osrc) and len(nums(src)) == 3 * 16 * 11
 
 
 def test_oracle_tables_loaded(oracle):
