@@ -13,6 +13,7 @@
 //             re-read), 1 = x[base + slot] (z parked in the output until the draw overwrites it),
 //             2 = z[slot] (a per-wave LDS array)
 //   NT      : element type of the shape vector (int for rpg_devroye, double for Logit's n)
+//   DOM     : stream domain (DOM_DRAW for rpg_devroye, DOM_OMEGA for a chain's omega draws)
 //   NLDS    : nvec is a per-wave LDS array indexed by slot (staged by the caller) instead of a
 //             global array indexed by base + slot: nothing on the refill path then waits on HBM
 #pragma once
@@ -23,6 +24,8 @@ namespace bl {
 // A lane's in-flight observation.  Self-contained: once an observation has been started nothing of
 // the list it came from (index list, staged mass, z) is read again, so the state survives the caller
 // rebuilding those for its next chunk.
+constexpr uint32_t kPg1BlkCap = 4000000u;   // Philox blocks per observation
+
 struct Pg1Slot {
   int64_t row = -1;         // index into x[] / global observation offset; -1 = idle
   int nrem = 0;             // PG(1,z) draws still to add (PolyaGamma::draw(int n, ...), :126-140)
@@ -35,7 +38,7 @@ struct Pg1Slot {
 // Runs the queue over `list[0..cnt)`.  drain = false: return as soon as the list is exhausted, leaving
 // the lanes that are still inside a draw in flight in L (the caller comes back with the next list, or
 // with an empty list and drain = true); drain = true: run until every lane is idle.
-template <int ZC, int ZSRC, typename NT, bool NLDS = false>
+template <int ZC, int ZSRC, typename NT, bool NLDS = false, uint32_t DOM = DOM_DRAW>
 __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const unsigned short* __restrict__ list,
                                                   int cnt, const double* __restrict__ z,
                                                   const double* __restrict__ sM, double* __restrict__ x,
@@ -64,7 +67,7 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
         pg1_par_finish(L.par);
         const uint64_t idx = idx0 + (uint64_t)row;
         L.c0 = (uint32_t)idx;
-        L.c1 = ctr1_of(idx, DOM_DRAW);
+        L.c1 = ctr1_of(idx, DOM);
         L.blk = 0;
         L.sum = 0.0;
         L.sm.fresh = true;
@@ -82,14 +85,15 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
         L.sum += 0.25 * L.sm.X;
         if (--L.nrem == 0) { x[L.row] = L.sum; L.row = -1; }
       }
-      if (L.blk > 4000000u) { st_flags |= ST_ITER_CAP; x[L.row] = L.sum; L.row = -1; }
+      // the reference's loops are uncapped (PolyaGamma.cpp:167,181); a lane that never exits would hang its wave
+      if (L.row >= 0 && L.blk > kPg1BlkCap) { st_flags |= ST_ITER_CAP; x[L.row] = L.sum; L.row = -1; }
     }
     if (!drain && next >= cnt) break;
   }
 }
 
 // One list, start to finish (every lane idle on return).
-template <int ZC, int ZSRC, typename NT, bool NLDS = false>
+template <int ZC, int ZSRC, typename NT, bool NLDS = false, uint32_t DOM = DOM_DRAW>
 __device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__ list, int cnt,
                                               const double* __restrict__ z, const double* __restrict__ sM,
                                               double* __restrict__ x, const NT* __restrict__ nvec, int nscalar,
@@ -97,7 +101,7 @@ __device__ __forceinline__ void devroye_queue(const unsigned short* __restrict__
                                               uint64_t lt_mask, int& st_flags)
 {
   Pg1Slot L;
-  devroye_queue_run<ZC, ZSRC, NT, NLDS>(L, true, list, cnt, z, sM, x, nvec, nscalar, base, idx0, epoch, k0, k1,
+  devroye_queue_run<ZC, ZSRC, NT, NLDS, DOM>(L, true, list, cnt, z, sM, x, nvec, nscalar, base, idx0, epoch, k0, k1,
                                         lt_mask, st_flags);
 }
 

@@ -7,7 +7,7 @@
 
 namespace bl {
 
-enum : int { ST_OK = 0, ST_ITER_CAP = 1, ST_BAD_SHAPE = 2, ST_ALT_FALLTHROUGH = 4 };
+enum : int { ST_OK = 0, ST_ITER_CAP = 1, ST_BAD_SHAPE = 2, ST_ALT_FALLTHROUGH = 4, ST_NOT_PD = 8 };
 
 // PolyaGamma::draw_sum_of_gammas, PolyaGamma.cpp:142-149 with bvec of :19-39.
 __device__ inline double pg_draw_sum_of_gammas(double b, double z, int trunc, Stream& r)

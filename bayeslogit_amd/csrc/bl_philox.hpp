@@ -44,6 +44,15 @@ BL_HD double u52(uint32_t hi, uint32_t lo)
   return (d - 1.0) + 0x1.0p-53;
 }
 
+// Key of the chain started by the `call`-th gibbs()/mult_gibbs() of the .C boundary after set_seed(seed): a
+// Philox block keyed by the seed in a domain of its own (4 = DOM_KEY), so that chains started by successive
+// calls, and the rpg_* calls around them, never read the same (key, counter) pair.
+BL_HD uint64_t chain_key(uint64_t seed, uint32_t call)
+{
+  const U4 o = philox4x32_10(call, 4u << 24, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return ((uint64_t)o.y << 32) | o.x;
+}
+
 // counter words 0..2 of stream (idx, domain, epoch); word 3 is the block number
 BL_HD uint32_t ctr1_of(uint64_t idx, uint32_t domain) { return ((uint32_t)(idx >> 32) & 0x00FFFFFFu) | (domain << 24); }
 

@@ -18,7 +18,13 @@
 
 namespace bl {
 
-enum : uint32_t { DOM_DRAW = 0, DOM_BETA = 1, DOM_DATA = 2 };
+// Stream domains (counter word 1, bits 24-31): disjoint counter spaces under one key.
+//   DOM_DRAW   rpg_* draws            idx = observation, epoch = call number of the .C boundary (or the caller's)
+//   DOM_BETA   beta draw of a chain   idx = 0,           epoch = sweep
+//   DOM_DATA   synthetic data
+//   DOM_OMEGA  omega draws of a chain idx = observation, epoch = sweep (mlogit: sweep (J-1) + category)
+//   DOM_KEY    key derivation: the chain key of the k-th gibbs()/mult_gibbs() call after set_seed
+enum : uint32_t { DOM_DRAW = 0, DOM_BETA = 1, DOM_DATA = 2, DOM_OMEGA = 3, DOM_KEY = 4 };
 
 constexpr double kPi = 3.141592653589793238462643383279502884197;
 

@@ -7,6 +7,7 @@
 
 #include "bl_gibbs_kernels.hpp"
 #include "bl_host.hpp"
+#include "bl_philox.hpp"
 
 struct bl_gibbs {
   int64_t N = 0;
@@ -272,7 +273,10 @@ int bl_gibbs_run(bl_gibbs* h, int samp, int burn, int constrain, double* beta_ou
     if (rc == BL_OK)
       e = hipMemcpyAsync(hist + (size_t)m * P, h->beta, sizeof(double) * P, hipMemcpyDeviceToDevice, h->stream);
   }
-  if (rc == BL_OK && e == hipSuccess && beta_out_host)
+  // a failed Cholesky ends the chain (the reference throws out of draw_beta, LogitWrapper.cpp:226-229): nothing is copied out
+  int st = BL_OK;
+  if (rc == BL_OK && e == hipSuccess) st = blh::collect_status(h->stream);
+  if (rc == BL_OK && e == hipSuccess && st != BL_ERR_NOT_PD && st != BL_ERR_HIP && beta_out_host)
     e = hipMemcpyAsync(beta_out_host, hist, sizeof(double) * (size_t)P * samp, hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   (void)hipFree(hist);
@@ -280,8 +284,7 @@ int bl_gibbs_run(bl_gibbs* h, int samp, int burn, int constrain, double* beta_ou
     blh::set_error(std::string("bl_gibbs_run: ") + hipGetErrorString(e));
     return BL_ERR_HIP;
   }
-  if (rc != BL_OK) return rc;
-  return blh::collect_status(h->stream);
+  return rc != BL_OK ? rc : st;
 }
 
 // Streaming / thinning / on-device moments; same chain as bl_gibbs_run.
@@ -364,6 +367,10 @@ int bl_gibbs_run_stream(bl_gibbs* h, int samp, int burn, int constrain, int thin
   }
   if (rc == BL_OK && e == hipSuccess && wstats) blk::launch_welford_finish(stats->w_var_dev, N, samp, h->stream);
   if (rc == BL_OK && e == hipSuccess && bstats) blk::launch_welford_finish(bmom.p + P, P, samp, h->stream);
+  // a failed Cholesky ends the chain (the reference throws out of draw_beta, LogitWrapper.cpp:226-229): no beta is copied out
+  int st = BL_OK;
+  if (rc == BL_OK && e == hipSuccess) st = blh::collect_status(h->stream);
+  if (st == BL_ERR_NOT_PD || st == BL_ERR_HIP) rc = st;
   if (rc == BL_OK && e == hipSuccess && beta_out_host)
     e = hipMemcpyAsync(beta_out_host, hist.p, sizeof(double) * (size_t)P * nkeep, hipMemcpyDeviceToHost, h->stream);
   if (rc == BL_OK && e == hipSuccess && stats && stats->beta_mean_host)
@@ -383,8 +390,7 @@ int bl_gibbs_run_stream(bl_gibbs* h, int samp, int burn, int constrain, int thin
     blh::set_error(std::string("bl_gibbs_run_stream: ") + hipGetErrorString(e));
     return BL_ERR_HIP;
   }
-  if (rc != BL_OK) return rc;
-  return blh::collect_status(h->stream);
+  return rc != BL_OK ? rc : st;
 }
 
 // ================================================================ .C boundary
@@ -395,7 +401,7 @@ void gibbs(double* wp, double* betap, double* yp, double* tXp, double* np, doubl
   if (!blh::ensure_device()) return;
   const int64_t n = *N;
   const int p = *P;
-  const uint64_t seed = blh::global_seed() ^ ((uint64_t)blh::next_epoch() << 40);
+  const uint64_t seed = bl::chain_key(blh::global_seed(), blh::next_epoch());   // bl_philox.hpp
   blh::DevBuf<double> dX, dy, dn;
   hipError_t e = dX.alloc((size_t)n * p);
   if (e == hipSuccess) e = dy.alloc(n);
@@ -547,7 +553,7 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
     printf("Error: mult_gibbs: bad arguments\nAborting Gibbs sampler.\n");
     return;
   }
-  const uint64_t seed = blh::global_seed() ^ ((uint64_t)blh::next_epoch() << 40);
+  const uint64_t seed = bl::chain_key(blh::global_seed(), blh::next_epoch());   // bl_philox.hpp
   hipStream_t s = nullptr;
   const size_t PPn = (size_t)p * p;
   blh::DevBuf<double> dX, dty, dn, dw, dbeta, dXB, dc, dZ, db0, dP0, dm0, dkap, db1, dxoc;

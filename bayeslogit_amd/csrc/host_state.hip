@@ -70,6 +70,10 @@ int collect_status(hipStream_t s)
     std::lock_guard<std::mutex> l(g_mu);
     g_flags = st;
   }
+  if (st & BL_ST_NOT_PD) {
+    set_error("posterior precision matrix is not positive definite (Cholesky factorisation failed)");
+    return BL_ERR_NOT_PD;
+  }
   if (st != 0) {
     set_error("sampler flags raised: " + std::to_string(st) +
               " (1 = iteration cap, 2 = bad shape, 4 = alt sampler fall-through)");

@@ -32,7 +32,7 @@ template <int MODE>
 __device__ __forceinline__ double weight_of(double psi, double n, uint64_t seed, uint64_t idx, uint32_t epoch, int& st)
 {
   if (MODE == blk::W_DRAW) {
-    return pg1_draw_n((int)n, psi, seed, idx, DOM_DRAW, epoch, st);   // Logit.hpp:287
+    return pg1_draw_n((int)n, psi, seed, idx, DOM_OMEGA, epoch, st);   // Logit.hpp:287
   } else {
     const double hpsi = psi * 0.5;                      // Logit.hpp:509-519
     if (fabs(hpsi) < 0.01)
@@ -137,7 +137,7 @@ __device__ __attribute__((noinline)) int draw_chunk(const unsigned short* list_,
   const uint64_t idx0 = uni64(idx0_);
   const uint32_t epoch = uni32(epoch_), k0 = uni32(k0_), k1 = uni32(k1_);
   int st_flags = 0;
-  devroye_queue<ZC, 2, int, true>(list, n, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
+  devroye_queue<ZC, 2, int, true, DOM_OMEGA>(list, n, sZw, sMw, w, sNw, 1, base, idx0, epoch, k0, k1, lt_mask, st_flags);
   return st_flags;
 }
 
@@ -182,7 +182,7 @@ __device__ __attribute__((noinline)) int draw_deferred(const uint32_t* list_, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     Pg1Slot L;
-    devroye_queue_run<2, 2, int, true>(L, true, sIdxw, n, sZw, sMw, w, sNw, 1, r0, idx0, epoch, k0, k1, lt_mask, st_flags,
+    devroye_queue_run<2, 2, int, true, DOM_OMEGA>(L, true, sIdxw, n, sZw, sMw, w, sNw, 1, r0, idx0, epoch, k0, k1, lt_mask, st_flags,
                                        list + seg);
     __builtin_amdgcn_wave_barrier();
   }
@@ -824,6 +824,9 @@ __device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* _
 __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
   const int P = a.P, t = threadIdx.x;
   double* A = a.work;                      // PP, then U
   double* S = a.work + (size_t)P * P;      // PP^{-1}
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
   __syncthreads();
   if (!wg_chol_upper(A, P, &bad)) {
     __syncthreads();
-    if (t == 0) atomicOr(a.status, 8);
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
     return;
   }
 
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
     __syncthreads();
     if (!wg_chol_lower(S, P, &bad)) {
       __syncthreads();
-      if (t == 0) atomicOr(a.status, 8);
+      if (t == 0) atomicOr(a.status, ST_NOT_PD);
       return;
     }
     for (int i = t; i < P; i += (int)blockDim.x) {
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
   wg_solve_U(A, mP, P, 1, P);
   if (!wg_chol_lower(S, P, &bad)) {     // L = chol(S,'L'), in place
     __syncthreads();
-    if (t == 0) atomicOr(a.status, 8);
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
     return;
   }
   if (P <= 256) {
@@ -1456,6 +1459,9 @@ __device__ __forceinline__ bool spec_group_w(int wave, const double* S, const do
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
   const int P = a.P, t = threadIdx.x, ld = P + 1;
   double* A = lds;                       // PP -> U
   double* S = A + P * ld;                // PP^{-1} -> L
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     // for the single-wave routines below)
     if (!lds_chol_upper(A, P, ld, &bad)) {
       __syncthreads();
-      if (t == 0) atomicOr(a.status, 8);
+      if (t == 0) atomicOr(a.status, ST_NOT_PD);
       return;
     }
     for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
@@ -1613,7 +1619,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
   __syncthreads();
   if (bad) {
-    if (t == 0) atomicOr(a.status, 8);
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
     return;
   }
   if (mode != blk::B_CONSTRAINED) return;
@@ -1824,6 +1830,9 @@ template <int RPL>
 __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
 {
   extern __shared__ double lds[];
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
   const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
   const int nrec = P * kRec;
   const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)

@@ -34,7 +34,9 @@ enum {
   BL_ERR_NOT_PD = 5       /* posterior precision not positive definite       */
 };
 /* sampler flag bits (device side ORs them into one word per call) */
-enum { BL_ST_ITER_CAP = 1, BL_ST_BAD_SHAPE = 2, BL_ST_ALT_FALLTHROUGH = 4 };
+enum { BL_ST_ITER_CAP = 1, BL_ST_BAD_SHAPE = 2, BL_ST_ALT_FALLTHROUGH = 4,
+       BL_ST_NOT_PD = 8 /* a Cholesky factorisation of the posterior precision failed: reported as BL_ERR_NOT_PD, fatal
+                           to the chain (the reference throws there and gibbs() aborts, LogitWrapper.cpp:226-229) */ };
 
 const char *bl_last_error(void);
 int         bl_last_sampler_flags(void);

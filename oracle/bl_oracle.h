@@ -45,7 +45,9 @@ typedef struct {
   uint64_t nunif;    /* uniforms consumed (diagnostic) */
 } bl_rng;
 
-enum { BL_DOM_DRAW = 0, BL_DOM_BETA = 1, BL_DOM_DATA = 2 };
+enum { BL_DOM_DRAW = 0, BL_DOM_BETA = 1, BL_DOM_DATA = 2, BL_DOM_OMEGA = 3, BL_DOM_KEY = 4 };
+/* key of the chain started by the call-th gibbs()/mult_gibbs() of the .C boundary after set_seed(seed) */
+uint64_t bl_chain_key(uint64_t seed, uint32_t call);
 
 void   bl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void   bl_rng_init(bl_rng *r, uint64_t seed, uint64_t idx, uint32_t domain, uint32_t epoch);

@@ -5,7 +5,7 @@
  *
  * RNG streams (DESIGN.md "RNG stream contract"): sweep s (burn-in sweeps
  * 0..burn-1, sampling sweeps burn..burn+samp-1) draws omega_i from
- * (seed, idx0+i, DOM_DRAW, epoch=s) and beta from (seed, 0, DOM_BETA, epoch=s).
+ * (seed, idx0+i, DOM_OMEGA, epoch=s) and beta from (seed, 0, DOM_BETA, epoch=s).
  */
 #include "bl_oracle.h"
 #include <math.h>
@@ -114,7 +114,7 @@ static void draw_w(double *w, const double *psi, const double *n, int64_t N,
 {
   for (int64_t i = 0; i < N; ++i) {
     bl_rng r;
-    bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_DRAW, epoch);
+    bl_rng_init(&r, seed, idx0 + (uint64_t)i, BL_DOM_OMEGA, epoch);
     w[i] = bl_pg_draw_devroye((int)n[i], psi[i], &r);
   }
 }

@@ -5,7 +5,7 @@
  * P0 P x P x (J-1), w N x (J-1) x samp, beta P x (J-1) x samp; column-major.
  *
  * RNG streams: sweep s, category j use epoch e = s*(J-1)+j: omega_i from
- * (seed, i, DOM_DRAW, e), beta_j from (seed, 0, DOM_BETA, e).
+ * (seed, i, DOM_OMEGA, e), beta_j from (seed, 0, DOM_BETA, e).
  */
 #include "bl_oracle.h"
 #include <math.h>
@@ -139,7 +139,7 @@ int bl_o_mult_gibbs(double *w, double *beta, const double *ty, const double *tX,
       double *wj = w ? w + (size_t)slot * N * U + (size_t)j * N : wscr;
       for (int64_t i = 0; i < N; ++i) {          /* draw_w -- :234-240 */
         bl_rng r;
-        bl_rng_init(&r, seed, (uint64_t)i, BL_DOM_DRAW, epoch);
+        bl_rng_init(&r, seed, (uint64_t)i, BL_DOM_OMEGA, epoch);
         wj[i] = bl_pg_draw_devroye((int)n[i], eta[i], &r);
       }
       /* draw_beta -- :242-258 */

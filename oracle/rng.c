@@ -29,6 +29,13 @@ void bl_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+uint64_t bl_chain_key(uint64_t seed, uint32_t call)
+{
+  uint32_t ctr[4] = {call, (uint32_t)BL_DOM_KEY << 24, 0, 0}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, out[4];
+  bl_philox4x32_10(ctr, key, out);
+  return ((uint64_t)out[1] << 32) | out[0];
+}
+
 void bl_rng_init(bl_rng *r, uint64_t seed, uint64_t idx, uint32_t domain, uint32_t epoch)
 {
   r->key[0] = (uint32_t)seed;

@@ -47,6 +47,7 @@ def lib():
         f.argtypes = list(args)
 
     sig("bl_philox4x32_10", None, C.POINTER(c_u32), C.POINTER(c_u32), C.POINTER(c_u32))
+    sig("bl_chain_key", c_u64, c_u64, c_u32)
     sig("bl_rng_init", None, rp, c_u64, c_u64, c_u32, c_u32)
     sig("bl_unif", c_d, rp)
     sig("bl_expon_rate", c_d, rp, c_d)
@@ -60,6 +61,7 @@ def lib():
     sig("bl_p_norm", c_d, c_d, C.c_int)
     sig("bl_p_gamma_rate", c_d, c_d, c_d, c_d)
     sig("bl_p_igauss", c_d, c_d, c_d, c_d)
+    sig("bl_pg_draw_devroye", c_d, C.c_int, c_d, rp)
     sig("bl_pg_a", c_d, C.c_int, c_d)
     sig("bl_pg_mass_texpon", c_d, c_d)
     sig("bl_pg_m1", c_d, c_d, c_d)
@@ -123,6 +125,11 @@ def rng(seed, idx=0, domain=0, epoch=0):
     r = BlRng()
     lib().bl_rng_init(C.byref(r), seed, idx, domain, epoch)
     return r
+
+
+def chain_key(seed, call=0):
+    """Key of the chain the call-th gibbs()/mult_gibbs() of the .C boundary starts after set_seed(seed)."""
+    return lib().bl_chain_key(seed, call)
 
 
 def philox(ctr, key):

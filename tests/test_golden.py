@@ -49,7 +49,8 @@ def test_oracle_reproduces_golden_gibbs(oracle):
     X, y, n = gibbs_problem()
     P = X.shape[1]
     for con in (0, 1):
-        w, beta = oracle.gibbs(y, X, n, np.zeros(P), np.eye(P) * 0.25, g["samp"], g["burn"], g["seed"], con)
+        assert oracle.chain_key(g["seed"], 0) == g["chain_key"]
+        w, beta = oracle.gibbs(y, X, n, np.zeros(P), np.eye(P) * 0.25, g["samp"], g["burn"], g["chain_key"], con)
         assert beta.tolist() == g[f"beta_constrain{con}"]
         assert w[-1, :8].tolist() == g[f"w_last_head_constrain{con}"]
     be, it = oracle.em(y, X, n)

@@ -161,6 +161,25 @@ def test_edge_cases(gpu, oracle):
     assert bl._lib.lib().bl_last_sampler_flags() & 2
     agree(x.cpu().numpy(), oracle.rpg_devroye(2, [-2, 1], [1.0, 1.0], 4))
     D.sync_status()   # flags were cleared by the failed sync
+    # shapes below 1 through rpg_alt / rpg_sp: refused and flagged, 0 returned (PolyaGammaAlt.cpp:207-210); h = 0 -> 0
+    hb = dev_t([0.5, 2.0, 0.0, -3.0, 7.0], gpu)
+    zb = dev_t([1.0, 1.0, 1.0, 1.0, 1.0], gpu)
+    for fn, href in ((D.rpg_alt, [0.0, 2.0, 0.0, 0.0, 7.0]), (D.rpg_sp, [0.0, 2.0, 0.0, 0.0, 7.0])):
+        x = fn(hb, zb, seed=4)
+        with pytest.raises(bl.BayesLogitError):
+            D.sync_status()
+        assert bl._lib.lib().bl_last_sampler_flags() & 2
+        xg = x.cpu().numpy()
+        assert xg[0] == 0 and xg[2] == 0 and xg[3] == 0 and xg[1] > 0 and xg[4] > 0
+        ref = oracle.rpg_alt(5, href, 1.0, 4) if fn is D.rpg_alt else oracle.rpg_sp(5, href, 1.0, 4)[0]
+        agree(xg, ref)
+    # task-queue chunk boundaries (1024 observations per wave chunk, 64 tasks per set-up batch), z = NaN
+    for n in (63, 64, 65, 1023, 1024, 1025, 5000):
+        hh = rng_h = np.random.default_rng(n).integers(3, 51, n).astype(float)
+        zz = np.random.default_rng(n + 1).normal(0, 1.5, n)
+        x = D.rpg_hybrid(dev_t(hh, gpu), dev_t(zz, gpu), seed=10, idx0=7)
+        D.sync_status()
+        agree(x.cpu().numpy(), oracle.rpg_hybrid(n, hh, zz, 10, 0, 7), 1e-9)
     # chunk boundaries of the per-class work queue (512 observations per wave chunk), both classes mixed,
     # shapes > 1, huge |z| (proposal mass underflows to 0), z = NaN (the reference falls through with NaN)
     rng = np.random.default_rng(8)

@@ -55,9 +55,16 @@ def test_set_bP_and_sweep_partial(oracle):
     beta = np.linspace(-0.3, 0.4, 7)
     PP, w = oracle.sweep_partial(X, n, beta, seed=5, sweep=3, idx0=10)
     assert np.allclose(PP, X.T @ (X * w[:, None]), rtol=1e-12) and np.array_equal(PP, PP.T)
-    # omega_i is PG((int) n_i, x_i.beta) on stream (seed, idx0+i, DRAW, sweep)
+    # omega_i is PG((int) n_i, x_i.beta) on stream (seed, idx0+i, DOM_OMEGA = 3, sweep)
+    import ctypes as C
     psi = np.array([sum(X[i, j] * beta[j] for j in range(7)) for i in range(300)])   # the oracle's summation order
-    assert np.allclose(w, oracle.rpg_devroye(300, n.astype(np.int32), psi, 5, 3, 10), rtol=1e-12, atol=0)
+    ref = []
+    for i in range(300):
+        r = oracle.rng(5, 10 + i, 3, 3)
+        ref.append(oracle.lib().bl_pg_draw_devroye(int(n[i]), psi[i], C.byref(r)))
+    assert np.allclose(w, ref, rtol=1e-12, atol=0)
+    # ... and is not what an rpg_devroye call of the same (seed, epoch) would read (DOM_DRAW)
+    assert not np.any(w == oracle.rpg_devroye(300, n.astype(np.int32), psi, 5, 3, 10))
 
 
 def test_unconstrained_beta_is_mvn(oracle):

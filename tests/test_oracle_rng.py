@@ -106,3 +106,23 @@ def test_qnorm_as241(oracle):
     ps = np.concatenate([10.0 ** np.linspace(-300, -1.2, 500), np.linspace(0.07, 0.93, 500)])
     q = np.array([L.bl_qnorm(p) for p in ps])
     assert np.allclose(q, stats.norm.ppf(ps), rtol=3e-15, atol=1e-15)
+
+
+def test_call_sequences_never_share_a_stream(oracle):
+    """set_seed(s); gibbs(); rpg_devroye(); ...: the chain started by the k-th gibbs() call reads streams
+    (chain_key(s, k), DOM_OMEGA / DOM_BETA, sweep), the j-th rpg_* call (s, DOM_DRAW, j).  No (key, counter) pair of
+    one is a pair of the other: the domains differ, and the derived key is a Philox output, not the seed."""
+    s = 0x42A7E5105EEDB00F
+    keys = [oracle.chain_key(s, k) for k in range(6)]
+    assert len(set(keys + [s])) == 7
+    L = oracle.lib()
+    seen = set()
+    for key, dom in [(s, 0)] + [(k, d) for k in keys for d in (1, 3)] + [(s, 3), (s, 1)]:
+        for epoch in range(4):
+            r = oracle.rng(key, 5, dom, epoch)
+            u = L.bl_unif(C.byref(r))
+            assert u not in seen
+            seen.add(u)
+    # chain_key is the documented Philox block: words (0, 1) of Philox(ctr = (call, DOM_KEY << 24, 0, 0), key = seed)
+    o = oracle.philox([3, 4 << 24, 0, 0], [s & 0xFFFFFFFF, s >> 32])
+    assert oracle.chain_key(s, 3) == (o[1] << 32) | o[0]
