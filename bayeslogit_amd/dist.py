@@ -27,11 +27,18 @@ def shard_range(N, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class ReplicaDivergence(RuntimeError):
+    """The ranks' redundantly drawn beta are no longer bit-identical."""
+
+
 class DistGibbs:
-    def __init__(self, shard, group=None):
+    def __init__(self, shard, group=None, check_every=0):
+        """check_every = k > 0: every k-th sweep verify that all ranks hold the same beta (one all-reduce of 2P
+        doubles); 0: only when verify_replicas() is called (run() calls it once at the end)."""
         self.shard = shard
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.check_every = int(check_every)
 
     def _all_reduce(self, t):
         if self.world > 1:
@@ -46,11 +53,26 @@ class DistGibbs:
         if beta0 is not None:
             s.set_beta(beta0)
 
+    def verify_replicas(self):
+        """Every rank draws beta redundantly from the same (seed, sweep) stream and the same all-reduced PP, so the
+        replicas must agree bit for bit; a collective that returned different bits on different ranks would let the
+        chains drift apart silently.  max over ranks of (beta, -beta): equal halves <=> identical replicas."""
+        if self.world == 1:
+            return
+        b = self.shard.beta()
+        t = torch.cat([b, -b])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        P = b.numel()
+        if not torch.equal(t[:P], -t[P:]):
+            raise ReplicaDivergence("beta differs between ranks (the all-reduced X'Omega X was not bit-identical everywhere)")
+
     def sweep(self, sweep, constrain=1, w_out=None):
         s = self.shard
         s.sweep_local(sweep, w_out)
         self._all_reduce(s.pp())
         s.draw_beta(sweep, constrain)
+        if self.check_every > 0 and (sweep + 1) % self.check_every == 0:
+            self.verify_replicas()
 
     def run(self, samp, burn, constrain=1):
         """burn + samp sweeps; returns beta history (samp, P) as a CPU tensor."""
@@ -64,4 +86,5 @@ class DistGibbs:
             self.sweep(sweep, constrain)
             hist.append(s.beta().clone())
             sweep += 1
+        self.verify_replicas()
         return torch.stack(hist).cpu()

@@ -30,6 +30,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz
 FP64_MFMA_PEAK_TFLOPS = 78.6    # AMD's MI355X figure for fp64 matrix (= the vector rate); MI355X_MICROARCH.md has no fp64 row
 BYTES_PER_DRAW = 16             # 8 B z in + 8 B x out (scalar shape)
+BYTES_PER_DRAW_VEC = 24         # 8 B h + 8 B z in + 8 B x out through the vector-shape rpg_hybrid signature
 
 
 def parse():
@@ -48,7 +49,14 @@ def parse():
     ap.add_argument("--c5", action="store_true", help="also time one GPU's shard of config C5 (12.5e6 x 256 per rank)")
     ap.add_argument("--c5-sweeps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--mixed", action="store_true", help="also time config C3 (mixed shapes)")
+    ap.add_argument("--no-mixed", action="store_true", help="skip config C3 (mixed shapes b in 1..50 through rpg_hybrid)")
+    ap.add_argument("--mixed", action="store_true", help="(default now; kept so that older command lines still parse)")
+    ap.add_argument("--mixed-steps", type=int, default=5)
+    ap.add_argument("--post-n", type=int, default=5000,
+                    help="rows of the problem on which a GPU chain and a CPU (oracle) chain are run on the same (X, y) and "
+                         "their posterior mean/sd compared (0 = skip)")
+    ap.add_argument("--post-samp", type=int, default=2000)
+    ap.add_argument("--cpu-gibbs-n", type=int, default=200_000, help="rows of the timed CPU Gibbs sample (10 sweeps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
     return ap.parse_args()
 
@@ -133,20 +141,100 @@ def cpu_baseline(draws_sample, ncores):
     return one, allc
 
 
-def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, chain=0):
-    """Gibbs sweeps/s on an N x P problem with rows sharded over the ranks: per sweep one pass over this
-    rank's rows (psi, omega, X' Omega X), one P*P all-reduce, the replicated P x P stage."""
-    lo, hi = shard_range(N, rank, world)
-    nl = hi - lo
-    X = torch.empty((nl, P), dtype=torch.float64, device=dev)
+def synth_logit(D, dev, N, P, lo=0):
+    """The C4 generator (SURVEY 8d): x_ij ~ N(0,1)/sqrt(P), last column 1; beta_true = |N(0,1)|, intercept -0.5;
+    y ~ Bernoulli(sigma(x.beta)); rows lo .. lo+N of the global problem."""
+    X = torch.empty((N, P), dtype=torch.float64, device=dev)
     D.fill_norm(X, 0.0, 1.0 / P ** 0.5, 20240003, idx0=lo * P)
     X[:, -1] = 1.0
     bt = torch.empty(P, dtype=torch.float64, device=dev)
     D.fill_norm(bt, 0.0, 1.0, 20240003, epoch=1)
     bt.abs_()
     bt[-1] = -0.5
-    y = torch.empty(nl, dtype=torch.float64, device=dev)
+    y = torch.empty(N, dtype=torch.float64, device=dev)
     D.fill_logit_y(y, X, bt, 20240003, epoch=2, idx0=lo)
+    return X, y, bt
+
+
+def batch_mcse(chain, nb=20):
+    """Monte-Carlo standard error of the column means of a (samp, P) chain by batch means."""
+    m = (chain.shape[0] // nb) * nb
+    bm = chain[:m].reshape(nb, m // nb, -1).mean(1)
+    return bm.std(0, ddof=1) / np.sqrt(nb)
+
+
+def cpu_gibbs(D, dev, n_time, P, post_n, post_samp):
+    """The Gibbs half of the CPU baseline: the oracle's restatement of Logit::gibbs (Logit.hpp:402-481: serial, as the
+    reference is) (a) timed for 10 sweeps on an n_time x P sample of the C4 problem, (b) run as a whole chain on a
+    post_n x P problem next to the GPU chain on the SAME (X, y, seed): posterior mean and sd of beta compared."""
+    sys.path.insert(0, os.path.join(HERE, "tests"))
+    import oracle_lib as O
+    out = {}
+    m0, P0 = np.zeros(P), np.eye(P) * 0.01
+    X, y, _ = synth_logit(D, dev, n_time, P)
+    Xh, yh = X.cpu().numpy(), y.cpu().numpy()
+    del X, y
+    t0 = time.perf_counter()
+    O.gibbs(yh, Xh, np.ones(n_time), m0, P0, 10, 0, 20240004, 1, store_w=False)
+    dt = time.perf_counter() - t0
+    out["timed"] = {"rows": n_time, "P": P, "sweeps": 10, "seconds": dt, "sweeps_per_s": 10 / dt, "cores": 1,
+                    "note": "oracle bl_o_gibbs (C restatement of Logit.hpp:402-481, constrained draw, serial like the "
+                            "reference: Notes/benchmarks.tex:103-104); per-sweep cost is linear in the rows"}
+    if post_n > 0:
+        burn, samp, seed = 200, post_samp, 20240005
+        X, y, bt = synth_logit(D, dev, post_n, P)
+        nn = torch.ones(post_n, dtype=torch.float64, device=dev)
+        shard = D.GibbsShard(X, y, nn, seed=seed)
+        shard.set_prior(m0, P0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bg = shard.run_stream(samp, burn, constrain=1)["beta"]
+        tg = time.perf_counter() - t0
+        shard.close()
+        Xh, yh = X.cpu().numpy(), y.cpu().numpy()
+        t0 = time.perf_counter()
+        _, bc = O.gibbs(yh, Xh, np.ones(post_n), m0, P0, samp, burn, seed, 1, store_w=False)
+        tc = time.perf_counter() - t0
+        same = np.all(np.abs(bg - bc) <= 1e-8 * (1.0 + np.abs(bc)), axis=1)
+        lock = int(np.argmin(same)) if not same.all() else samp
+        se = np.sqrt(batch_mcse(bg) ** 2 + batch_mcse(bc) ** 2)
+        zmax = float(np.max(np.abs(bg.mean(0) - bc.mean(0)) / np.maximum(se, 1e-300)))
+        sdr = bg.std(0, ddof=1) / bc.std(0, ddof=1)
+        out["posterior"] = {
+            "problem": f"C4 generator at N={post_n}, P={P}, prior N(0, 100 I), beta_0 = 0, burn {burn} + samp {samp}, "
+                       f"constrained draw (the reference's active draw), chain seed {seed} on both",
+            "gpu_seconds": tg, "cpu_seconds": tc, "cpu_cores": 1,
+            "sweeps_identical_to_1e-8_before_the_chains_part": lock,
+            "max_abs_diff_of_posterior_means_in_mcse": zmax,
+            "sd_ratio_gpu_over_cpu_min_max": [float(sdr.min()), float(sdr.max())],
+            "tolerance": "posterior means within 5 combined batch-means MCSE, posterior sds within 25 % "
+                         "(chains of 2000 correlated draws); fp64 both sides",
+            "within_tolerance": bool(zmax < 5.0 and sdr.min() > 0.75 and sdr.max() < 1.25),
+            "beta_mean_gpu_head": [float(v) for v in bg.mean(0)[:3]], "beta_mean_cpu_head": [float(v) for v in bc.mean(0)[:3]],
+            "beta_sd_gpu_head": [float(v) for v in bg.std(0, ddof=1)[:3]], "beta_sd_cpu_head": [float(v) for v in bc.std(0, ddof=1)[:3]],
+        }
+    return out
+
+
+def cpu_hybrid(ncores, sample=2_000_000):
+    """C3's CPU figure: the oracle's literal restatement of rpg_hybrid's loop (LogitWrapper.cpp:129-167 over
+    PolyaGamma*.cpp) on a bounded sample, OpenMP schedule(dynamic) over the host cores."""
+    sys.path.insert(0, os.path.join(HERE, "tests"))
+    import oracle_lib as O
+    rng = np.random.default_rng(20240001)
+    h = rng.integers(1, 51, sample).astype(float)
+    z = rng.normal(0.0, 2 ** 0.5, sample)
+    t0 = time.perf_counter()
+    O.rpg_hybrid(sample, h, z, 20240002, threads=ncores, literal=True)
+    return sample / (time.perf_counter() - t0)
+
+
+def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, chain=0):
+    """Gibbs sweeps/s on an N x P problem with rows sharded over the ranks: per sweep one pass over this
+    rank's rows (psi, omega, X' Omega X), one P*P all-reduce, the replicated P x P stage."""
+    lo, hi = shard_range(N, rank, world)
+    nl = hi - lo
+    X, y, bt = synth_logit(D, dev, nl, P, lo)
     nn = torch.ones(nl, dtype=torch.float64, device=dev)
     shard = D.GibbsShard(X, y, nn, seed=20240004, idx0=lo)
     drv = DistGibbs(shard)
@@ -320,7 +408,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "C2: N=1e8 PG(1,z) draws per GPU, z~Unif(0,4) (Devroye lane path)",
+        "config": {"workload": ("C2: " if n == 100_000_000 else "C2 at reduced size: ") +
+                               f"N={n:.3g} PG(1,z) draws per GPU, z~Unif(0,4) (Devroye lane path)",
                    "draws_per_gpu_per_step": n, "rng": "philox4x32-10, one stream per observation",
                    "sample_mean": mean_x},
         "roofline": {
@@ -335,7 +424,11 @@ def main():
             # the binding resource (same PMC summary; per launch of the default 1e8-draw workload)
             "valu": {k: {"wave_insts_per_launch": pmc_entry(k).get("valu_insts_per_launch"),
                          "busy_frac_of_cu_cycles": pmc_entry(k).get("valu_busy_frac"),
-                         "issue_slot_frac_lower_bound": pmc_entry(k).get("valu_issue_frac_min")}
+                         "issue_slot_frac_lower_bound": pmc_entry(k).get("valu_issue_frac_min"),
+                         "wait_frac_of_wave_cycles": pmc_entry(k).get("wait_any_frac"),
+                         "issue_stall_frac_of_wave_cycles": pmc_entry(k).get("wait_inst_frac"),
+                         "salu_insts_per_valu_inst": pmc_entry(k).get("salu_per_valu"),
+                         "lds_bank_conflict_frac_of_lds_cycles": pmc_entry(k).get("lds_conflict_frac")}
                      for k in ("k_rpg_devroye<1>", "k_rpg_devroye<2>")},
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": BYTES_PER_DRAW * n,
@@ -344,16 +437,36 @@ def main():
     }
     del z, x
 
-    if a.mixed:
+    if not a.no_mixed:
         zz = torch.empty(n, dtype=torch.float64, device=dev)
         hh = torch.empty(n, dtype=torch.float64, device=dev)
         xx = torch.empty(n, dtype=torch.float64, device=dev)
         D.fill_norm(zz, 0.0, 2.0 ** 0.5, 20240001, idx0=idx0)
         D.fill_shape(hh, 50, 20240001, epoch=1, idx0=idx0)
-        w3, k3 = timed_steps(lambda: D.rpg_hybrid(hh, zz, seed=20240002, idx0=idx0, out=xx), 3, 1, world, dev)
+        w3, k3 = timed_steps(lambda: D.rpg_hybrid(hh, zz, seed=20240002, idx0=idx0, out=xx), a.mixed_steps, 1, world, dev)
         D.sync_status()
-        out["mixed"] = {"workload": "C3: N=1e8 b in {1..50}, z~N(0,sd^2=2)", "M_draws_per_s": n * world * 3 / w3 / 1e6,
-                        "ms_per_step": w3 / 3 * 1e3}
+        gb3 = BYTES_PER_DRAW_VEC * n / (k3 * 1e-3) / 1e9
+        tq = {k: pmc_entry(k) for k in ("bl::k_rpg_tasks<bl::SpPolicy>", "bl::k_rpg_tasks<bl::AltPolicy>")}
+        out["mixed"] = {
+            "workload": ("C3: " if n == 100_000_000 else "C3 at reduced size: ") +
+                        f"N={n:.3g} draws per GPU, b in {{1..50}} (4 % Devroye, 22 % alternating series, 74 % saddle point), "
+                        "z~N(0,sd^2=2), through rpg_hybrid",
+            "value": n * world * a.mixed_steps / w3 / 1e6, "unit": "M draws/s", "M_draws_per_s": n * world * a.mixed_steps / w3 / 1e6,
+            "steps": a.mixed_steps, "ms_per_step": w3 / a.mixed_steps * 1e3, "sample_mean": xx.mean().item(),
+            "roofline": {
+                "kernel": "k_rpg_tasks<SpPolicy> + k_rpg_tasks<AltPolicy> + k_rpg_hybrid_class<2,5,1> (one launch per sampler "
+                          "class) behind a zeroing memset",
+                "bound": "hbm", "limiter": "valu (scalar fp64 transcendental work; see the valu object)",
+                "achieved": gb3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb3 / HBM_PEAK_GBS,
+                "traffic": (sum(v.get("hbm_bytes_per_launch", 0.0) for v in tq.values()) or None) if n == 100_000_000 else None,
+                "traffic_source": c2_traffic_src, "kernel_ms": k3, "algorithmic_bytes_per_launch": BYTES_PER_DRAW_VEC * n,
+                "valu": {k: {"wave_insts_per_launch": v.get("valu_insts_per_launch"),
+                             "busy_frac_of_cu_cycles": v.get("valu_busy_frac"),
+                             "issue_slot_frac_lower_bound": v.get("valu_issue_frac_min"),
+                             "wait_frac_of_wave_cycles": v.get("wait_any_frac"),
+                             "issue_stall_frac_of_wave_cycles": v.get("wait_inst_frac")} for k, v in tq.items()},
+            },
+        }
         del zz, hh, xx
 
     # ---------------------------------------------------------------- C4: Gibbs sweeps
@@ -376,6 +489,19 @@ def main():
                       f"OpenMP schedule(dynamic) as PolyaGammaOMP.h:61-71; 1-core rate on {min(sample, 4_000_000)} draws",
             "one_core_M_draws_per_s": one / 1e6,
         }
+        if not a.no_mixed:
+            out["cpu_baseline"]["mixed_M_draws_per_s"] = cpu_hybrid(ncores) / 1e6
+            out["cpu_baseline"]["mixed_sample"] = ("2000000 draws of the C3 mix, oracle's literal restatement of rpg_hybrid "
+                                                  f"(LogitWrapper.cpp:129-167), OpenMP on {ncores} cores")
+        if not a.no_gibbs:
+            cg = cpu_gibbs(D, dev, a.cpu_gibbs_n, a.gibbs_p, a.post_n, a.post_samp)
+            tm = cg["timed"]
+            tm["sweeps_per_s_extrapolated_to_gibbs_n"] = tm["sweeps_per_s"] * tm["rows"] / a.gibbs_n
+            tm["extrapolation"] = f"linear in rows: x {tm['rows']}/{a.gibbs_n}"
+            out["cpu_baseline"]["gibbs"] = tm
+            out["gibbs"]["vs_cpu_1_core_extrapolated"] = out["gibbs"]["value"] / tm["sweeps_per_s_extrapolated_to_gibbs_n"]
+            if "posterior" in cg:
+                out["gibbs"]["posterior_vs_cpu"] = cg["posterior"]
 
     if rank == 0:
         print(json.dumps(out))

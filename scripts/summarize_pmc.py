@@ -13,6 +13,13 @@ The JSON holds, per kernel and per launch:
   valu_issue_frac_min    = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x gpu_cycles): issue-slot use if
                            every instruction were full rate (fp64 transcendental-seed and 32-bit
                            integer multiplies are slower, so this is a lower bound)
+and, from the "stall" pass (what the waves do in the cycles no VALU instruction of theirs executes;
+MI355X_MICROARCH.md, rocprofv3 PMC slots: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES):
+  wait_any_frac          = SQ_WAIT_ANY / SQ_WAVE_CYCLES        wave parked on s_waitcnt / a barrier
+  wait_inst_frac         = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   issue stall (dependency / pipe busy)
+  active_inst_frac       = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES an instruction of the wave executing
+  salu_per_valu          = SQ_INSTS_SALU / SQ_INSTS_VALU
+  lds_conflict_frac      = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 """
 import collections
 import csv
@@ -21,10 +28,10 @@ import json
 import sys
 
 tag = sys.argv[1]
-KEEP = ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce")
+KEEP = ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce", "k_sweep")
 SIMDS = 256 * 4
 summary = collections.defaultdict(dict)
-for kind in ("fetch", "write", "valu"):
+for kind in ("fetch", "write", "valu", "stall"):
     files = glob.glob(f"gpurun_out/pmc_{kind}_{tag}/**/*counter_collection.csv", recursive=True)
     if not files:
         print(kind, "no counter file")
@@ -40,7 +47,8 @@ for kind in ("fetch", "write", "valu"):
             continue
         means = {c: sum(v) / len(v) for c, v in cs.items()}
         print(" ", name[:90], {c: (m, len(cs[c])) for c, m in means.items()})
-        summary[name].update(means)
+        for c, m in means.items():
+            summary[name].setdefault(c, m)        # SQ_INSTS_VALU / SQ_WAVE_CYCLES are in two passes: keep the first
 
 out = {}
 for name, m in summary.items():
@@ -63,6 +71,15 @@ for name, m in summary.items():
                 e["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] / (256.0 * cyc)
         if m.get("SQ_WAVES"):
             e["waves"] = m["SQ_WAVES"]
+    if m.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in m:
+        wc = m["SQ_WAVE_CYCLES"]
+        e["wait_any_frac"] = m["SQ_WAIT_ANY"] / wc
+        e["wait_inst_frac"] = m.get("SQ_WAIT_INST_ANY", 0.0) / wc
+        e["active_inst_frac"] = m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc
+        if m.get("SQ_INSTS_VALU"):
+            e["salu_per_valu"] = m.get("SQ_INSTS_SALU", 0.0) / m["SQ_INSTS_VALU"]
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
     out[short] = e
 with open(f"gpurun_out/pmc_summary_{tag}.json", "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
