@@ -55,12 +55,12 @@ struct AltPar {       // per (h, z): the part of draw_abridged that draws nothin
   double t;           // trunc_schedule[floor((h-1) 100)], :124-125
   double fz;          // rate_z = pi^2/8 + Z^2/2, :128
   double lfz;         // log fz
-  double p, ip, iq;   // prob_right, :131, and 1/p, 1/(1-p) for the recycling
+  double p;           // prob_right, :131
   double R;           // t/h^2, :9
   double ic0, omc, log_m;   // Dagpunar's constants for Gamma(h, 1) left-truncated at t fz: 1/c0, 1 - c0, log M
   double cR;          // log[(4/pi)^h Gamma(h+1) / sqrt(2 pi)]: a_0/g_tilde right of t without its X-dependent part
 };
-constexpr int kAltParDoubles = 13;
+constexpr int kAltParDoubles = 11;
 
 struct AltLane {
   int state;          // 0: the attempt starts a new trial (:142-153); 1: retry inside the left piece; 2: inside the right piece
@@ -123,8 +123,6 @@ BL_HD AltPar alt_par(double h, double z, double t, int& status)
   }
   const double wr = bl_exp(h * (kAltLogHalfPi - p.lfz)) * q;
   p.p = wr / (wr + wl);                                      // :131
-  p.ip = 1.0 / p.p;
-  p.iq = 1.0 / (1.0 - p.p);
   p.R = bl_div(t, h * h);
   // Dagpunar (Code/R/Ch.R:83-114): a = h, b = t fz; a == 1: the exponential, :88-89
   if (h == 1.0) {
@@ -147,7 +145,8 @@ BL_HD bool alt_attempt(AltLane& s, const AltPar& p, double u1, double u2, int& s
   const double h = p.h, t = p.t;
   const bool fresh = s.state == 0;
   const bool right = fresh ? u1 < p.p : s.state == 2;                                  // :149
-  const double w = alt_clamp(fresh ? (right ? u1 * p.ip : (u1 - p.p) * p.iq) : u1);
+  // the recycled uniform: u1/p given {u1 < p}, (u1 - p)/(1 - p) otherwise
+  const double w = alt_clamp(fresh ? bl_div(right ? u1 : u1 - p.p, right ? p.p : 1.0 - p.p) : u1);
   const bool big = !right && !(p.Z * t < h);             // left piece with mu = h/Z <= t, :81 (Z = 0: mu = inf)
   double X = 0.0, logX = 0.0, vnum = u2, vden = 1.0;
   bool retry = false;

@@ -44,19 +44,24 @@ constexpr double kSpSqrtHalf = 0.70710678118654752440084436210485;
 constexpr double kSpWMin = 0x1.0p-53, kSpWMax = 1.0 - 0x1.0p-53;
 constexpr int kSpVtInt = 16, kSpVtDeg = 10;
 
-struct SpPar {        // per (n, z): PolyaGammaSP.cpp:171-229
+// Per (n, z): what the set-up of PolyaGammaSP.cpp:171-229 leaves for the proposals.  The test F U < sp_approx(X)
+// (:245-257) is run on D = log sp_approx - log F, in which the constants of both sides are folded:
+//   left  of md: D = -log(K2)/2 + n (L - (v/2 + Z2h) X) + 3/2 log X + cL1 X + n/(2X) - cL0
+//                cL0 = log(al)/2 + n il + n/(2 md) - n log cosh Z,  cL1 = n rl                       (:245-246)
+//   right of md: D = -log(K2)/2 + n (L - (v/2 + Z2h) X) - (n - 1) log X + cR1 X - cR0
+//                cR0 = log(ar)/2 + n ir - n log md - n log cosh Z,  cR1 = n rr                       (:251-252)
+// with (v, L = -log cos_rt v, K2) of X from sp_vlk; lcn = log(n / 2 pi)/2 is on both sides and drops out.
+struct SpPar {
   double n;
-  double Z2;          // (|z|/2)^2
-  double md, imd, logmd;
-  double lcZ;         // log cosh(|z|/2)
-  double lhal, lhar;  // log(al)/2, log(ar)/2, :190-191
-  double rl, il, rr, ir;   // tangent lines: -slope, intercept, :201-204
+  double Z2h;         // (|z|/2)^2 / 2
+  double md;          // 1.1 x the mode: where the two pieces meet, :175
   double mu;          // 1/sqrt(2 rl): mean of the left piece's inverse Gaussian, :244
-  double pl, ipl, iql;     // wl/(wl + wr), :226-227, and the recycling reciprocals
+  double pl;          // wl/(wl + wr), :226-227
   double b, mdb, lmdb;     // ltgamma(n, n rr, md): b = md n rr; md/b; log(md/b)
   double ic0, omc, log_m;  // Dagpunar's constants for Gamma(n, 1) left-truncated at b
+  double cL0, cL1, cR0, cR1;
 };
-constexpr int kSpParDoubles = 22;
+constexpr int kSpParDoubles = 15;
 
 struct SpLane {
   int state;          // 0: the attempt starts a new iteration (:241); 1: retry inside the left piece; 2: inside the right piece
@@ -116,56 +121,55 @@ BL_HD void sp_vlk(const double* __restrict__ vt, double x, double logx, double& 
 BL_HD SpPar sp_par(double n, double z, const double* __restrict__ vt, int& status)
 {
   SpPar p;
+  double lcZ, imd, logmd, lhal, lhar, rl, il, rr, ir;   // log cosh Z; 1/md, log md; log(al)/2, log(ar)/2 (:190-191); tangent lines (:201-204)
   const double Z = 0.5 * fabs(z);                                            // :172
   const double Z2 = Z * Z;
   const double e2 = bl_exp(-2.0 * Z);
   const bool zbig = Z2 > 1e-6;
   const double xl = zbig ? bl_div(1.0 - e2, (1.0 + e2) * Z) : 1.0;           // y_func(-z^2), :78-90, :174
-  p.lcZ = Z + bl_log(1.0 + e2) - kSpLn2;
+  lcZ = Z + bl_log(1.0 + e2) - kSpLn2;
   const double md = xl * 1.1, xr = xl * 1.2;                                 // :175-176
   const double logxl = bl_log(xl);
   p.n = n;
-  p.Z2 = Z2;
+  p.Z2h = 0.5 * Z2;
   p.md = md;
-  p.imd = bl_div(1.0, md);
-  p.logmd = logxl + kSpLog1p1;
+  imd = bl_div(1.0, md);
+  logmd = logxl + kSpLog1p1;
   const double logxr = logxl + kSpLog1p2;
   double vmd, Lmd, lK2md, vr, Lr, lK2r;
-  sp_vlk(vt, md, p.logmd, vmd, Lmd, lK2md);                                  // :182-188
+  sp_vlk(vt, md, logmd, vmd, Lmd, lK2md);                                  // :182-188
   sp_vlk(vt, xr, logxr, vr, Lr, lK2r);
-  p.lhal = 0.5 * (3.0 * p.logmd - lK2md);                                    // log(md^3 / K2md)/2, :190
-  p.lhar = 0.5 * (2.0 * p.logmd - lK2md);                                    // :191
+  lhal = 0.5 * (3.0 * logmd - lK2md);                                    // log(md^3 / K2md)/2, :190
+  lhar = 0.5 * (2.0 * logmd - lK2md);                                    // :191
   // tangent to eta at xl, :197: v(xl) = -Z^2, t = 0, phi(xl) = 0; where y_func returned 1, v_eval(1) = 0
   const double ixl = zbig ? bl_div(1.0, xl) : 1.0;
   const double tl = zbig ? 0.0 : 0.5 * Z2;
-  const double phil = zbig ? 0.0 : p.lcZ - tl * xl;
-  p.rl = tl + 0.5 * ixl * ixl;                                               // delta' = 0.5/x^2 left of md, :109-112
-  p.il = phil - 0.5 * (p.imd - ixl) + p.rl * xl;                             // :144
+  const double phil = zbig ? 0.0 : lcZ - tl * xl;
+  rl = tl + 0.5 * ixl * ixl;                                               // delta' = 0.5/x^2 left of md, :109-112
+  il = phil - 0.5 * (imd - ixl) + rl * xl;                             // :144
   // tangent at xr, :198: delta = log xr - log md, delta' = 1/xr, :105-107
   const double tr = 0.5 * vr + 0.5 * Z2;
-  const double phir = p.lcZ + Lr - tr * xr;
-  p.rr = tr + bl_div(1.0, xr);
-  p.ir = phir - (kSpLog1p2 - kSpLog1p1) + p.rr * xr;
-  const double rt2rl = bl_sqrt(2.0 * p.rl);                                  // :210
+  const double phir = lcZ + Lr - tr * xr;
+  rr = tr + bl_div(1.0, xr);
+  ir = phir - (kSpLog1p2 - kSpLog1p1) + rr * xr;
+  const double rt2rl = bl_sqrt(2.0 * rl);                                  // :210
   p.mu = bl_div(1.0, rt2rl);
   // log wl, :217-218.  p_igauss(md; mu, n) = 1 - exp(-A1^2/2) [erfcx(A1/sqrt 2) - erfcx(A2/sqrt 2)]/2 with
   // A1 = sqrt(n/md)(md/mu - 1), A2 = sqrt(n/md)(md/mu + 1)
-  const double sn = bl_sqrt(n * p.imd);
+  const double sn = bl_sqrt(n * imd);
   const double A1 = sn * (md * rt2rl - 1.0), A2 = sn * (md * rt2rl + 1.0);
   const double pig =
       1.0 - 0.5 * bl_exp(-0.5 * A1 * A1) * (erfcx_pos(A1 * kSpSqrtHalf) - erfcx_pos(A2 * kSpSqrtHalf));
   const double logn = bl_log(n);
-  const double lwl = p.lhal + n * (p.il - rt2rl + 0.5 * p.imd) + bl_log(pig);
+  const double lwl = lhal + n * (il - rt2rl + 0.5 * imd) + bl_log(pig);
   // log wr, :220-222: Gamma(n) Q(n, x) = exp(-x) x^n CF(n, x), x = n rr md
-  const double x = n * p.rr * md;
+  const double x = n * rr * md;
   const double cf = upper_gamma_cf(n, x, status);
-  const double lwr = p.lhar + 0.5 * (logn - kSpLog2Pi) + n * p.ir - x + bl_log(cf);
+  const double lwr = lhar + 0.5 * (logn - kSpLog2Pi) + n * ir - x + bl_log(cf);
   p.pl = 1.0 / (1.0 + bl_exp(lwr - lwl));                                    // :226-227
-  p.ipl = 1.0 / p.pl;
-  p.iql = 1.0 / (1.0 - p.pl);
   p.b = x;
   p.mdb = bl_div(md, x);
-  p.lmdb = -(logn + bl_log(p.rr));                                           // log(md / (n rr md))
+  p.lmdb = -(logn + bl_log(rr));                                           // log(md / (n rr md))
   if (n == 1.0) {                                                            // a == 1: the exponential, Ch.R:88-89
     p.ic0 = 1.0; p.omc = 0.0; p.log_m = 0.0;
   } else {
@@ -175,6 +179,10 @@ BL_HD SpPar sp_par(double n, double z, const double* __restrict__ vt, int& statu
     p.omc = 1.0 - c0;
     p.log_m = d3 * (bl_log(bl_div(d3, p.omc)) - 1.0);
   }
+  p.cL0 = lhal + n * (il + 0.5 * imd - lcZ);
+  p.cL1 = n * rl;
+  p.cR0 = lhar + n * (ir - logmd - lcZ);
+  p.cR1 = n * rr;
   return p;
 }
 
@@ -185,8 +193,9 @@ BL_HD bool sp_attempt(SpLane& s, const SpPar& p, const double* __restrict__ vt, 
   const double n = p.n;
   const bool fresh = s.state == 0;
   const bool left = fresh ? u1 < p.pl : s.state == 1;                                  // :243
-  const double w = sp_clamp(fresh ? (left ? u1 * p.ipl : (u1 - p.pl) * p.iql) : u1);
-  double X, logX, logF, vnum, vden;
+  // the recycled uniform: u1/pl given {u1 < pl}, (u1 - pl)/(1 - pl) otherwise
+  const double w = sp_clamp(fresh ? bl_div(left ? u1 : u1 - p.pl, left ? p.pl : 1.0 - p.pl) : u1);
+  double X, logX, D, vnum, vden;      // D: the side's part of log sp_approx - log F that does not need v(X)
   bool retry;
   if (left) {
     // rtigauss(mu, n, md), :244: mu <= md always (mu <= xl), so r.igauss until <= md, :69-73
@@ -206,7 +215,7 @@ BL_HD bool sp_attempt(SpLane& s, const SpPar& p, const double* __restrict__ vt, 
     const bool xok = X > 1e-300 && X < 1e300;
     logX = xok ? bl_log(X) : log(X);
     const double iX = xok ? bl_div(1.0, X) : 1.0 / X;
-    logF = p.lhal - 1.5 * logX + n * (p.il - p.rl * X) + 0.5 * n * (p.imd - iX);      // :245-246 without lcn
+    D = 1.5 * logX + p.cL1 * X + 0.5 * n * iX - p.cL0;                                 // -log F + n log cosh Z, :245-246
   } else {
     // r.ltgamma(n, n rr, md), :250
     const double E = -bl_log(w);
@@ -218,7 +227,7 @@ BL_HD bool sp_attempt(SpLane& s, const SpPar& p, const double* __restrict__ vt, 
     vden = rho;
     X = x * p.mdb;                                                                      // trunc (x / b)
     logX = lx + p.lmdb;
-    logF = p.lhar + n * (p.ir - p.rr * X) + n * (logX - p.logmd) - logX;               // :251-252 without lcn
+    D = p.cR1 * X - (n - 1.0) * logX - p.cR0;                                          // -log F + n log cosh Z, :251-252
   }
   if (retry) {
     s.state = left ? 1 : 2;
@@ -227,11 +236,10 @@ BL_HD bool sp_attempt(SpLane& s, const SpPar& p, const double* __restrict__ vt, 
   const double vu = sp_clamp(bl_div(vnum, vden));
   double v, L, lK2;
   sp_vlk(vt, X, logX, v, L, lK2);
-  const double phi = p.lcZ + L - (0.5 * v + 0.5 * p.Z2) * X;                            // :157
-  const double logspa = -0.5 * lK2 + n * phi;                                          // :165 without lcn
+  D += n * (L - (0.5 * v + p.Z2h) * X) - 0.5 * lK2;                                    // + log sp_approx - n log cosh Z, :157-165
   s.state = 0;
   s.X = X;
-  accepted = vu < bl_exp(logspa - logF);                                               // F U < spa, :257
+  accepted = vu < bl_exp(D);                                                           // F U < spa, :257
   return true;
 }
 

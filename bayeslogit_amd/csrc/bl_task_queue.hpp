@@ -29,11 +29,12 @@
 namespace bl {
 
 constexpr int kTqBlock = 256;      // 4 wavefronts
-constexpr int kTqChunk = 1024;     // observations per wave per chunk (task list: <= 2 per observation)
+constexpr int kTqChunk = 512;      // observations per wave per chunk (task list: <= 2 per observation)
 
 // ---- saddle-point policy: one task per observation
 struct SpPolicy {
   static constexpr int kCls = CLS_SP;
+  static constexpr int kWavesPerSimd = 3;      // 165 registers per lane
   static constexpr int kStageDoubles = kSpParDoubles;
   static constexpr int kMaxTasksPerObs = 1;
   static constexpr bool kNeedsVtab = true;
@@ -45,8 +46,8 @@ struct SpPolicy {
                                                const double* __restrict__ vt, int& ndraws, uint32_t& blk0, int& status)
   {
     const SpPar p = sp_par(h, z, vt, status);
-    const double v[kSpParDoubles] = {p.n,  p.Z2, p.md, p.imd, p.logmd, p.lcZ, p.lhal, p.lhar, p.rl,  p.il,  p.rr,
-                                     p.ir, p.mu, p.pl, p.ipl, p.iql,   p.b,   p.mdb,  p.lmdb, p.ic0, p.omc, p.log_m};
+    const double v[kSpParDoubles] = {p.n,   p.Z2h, p.md,    p.mu,  p.pl,  p.b,   p.mdb, p.lmdb,
+                                     p.ic0, p.omc, p.log_m, p.cL0, p.cL1, p.cR0, p.cR1};
 #pragma unroll
     for (int f = 0; f < kSpParDoubles; ++f) st[f * 64 + slot] = v[f];
     ndraws = 1;
@@ -59,8 +60,7 @@ struct SpPolicy {
     double v[kSpParDoubles];
 #pragma unroll
     for (int f = 0; f < kSpParDoubles; ++f) v[f] = st[f * 64 + slot];
-    const SpPar p{v[0],  v[1],  v[2],  v[3],  v[4],  v[5],  v[6],  v[7],  v[8],  v[9],  v[10],
-                  v[11], v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], v[20], v[21]};
+    const SpPar p{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14]};
     sp_task_start(T, p, idx, DOM_DRAW);
   }
 
@@ -81,6 +81,7 @@ struct SpPolicy {
 // ---- alternating-series policy: group B (the remainder) always, group A (draws at shape 4) when h >= 5
 struct AltPolicy {
   static constexpr int kCls = CLS_ALT;
+  static constexpr int kWavesPerSimd = 3;      // 147 registers per lane (at 4: 128 with 4 spilled doubles, and no faster)
   static constexpr int kStageDoubles = kAltParDoubles;
   static constexpr int kMaxTasksPerObs = 2;
   static constexpr bool kNeedsVtab = false;
@@ -103,7 +104,7 @@ struct AltPolicy {
     alt_groups(h, nA, hB, nB);
     const double hs = group ? 4.0 : hB;                          // group 1 = A, PolyaGammaAlt.cpp:216-217
     const AltPar p = alt_par(hs, z, alt_trunc_of(kTruncSchedule, hs), status);
-    const double v[kAltParDoubles] = {p.h, p.Z, p.t, p.fz, p.lfz, p.p, p.ip, p.iq, p.R, p.ic0, p.omc, p.log_m, p.cR};
+    const double v[kAltParDoubles] = {p.h, p.Z, p.t, p.fz, p.lfz, p.p, p.R, p.ic0, p.omc, p.log_m, p.cR};
 #pragma unroll
     for (int f = 0; f < kAltParDoubles; ++f) st[f * 64 + slot] = v[f];
     ndraws = group ? nA : nB;
@@ -116,7 +117,7 @@ struct AltPolicy {
     double v[kAltParDoubles];
 #pragma unroll
     for (int f = 0; f < kAltParDoubles; ++f) v[f] = st[f * 64 + slot];
-    const AltPar p{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]};
+    const AltPar p{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
     alt_task_start(T, p, ndraws, idx, DOM_DRAW, blk0);
   }
 
@@ -139,7 +140,7 @@ struct AltPolicy {
 // rpg_sp): every h != 0 is a member (LogitWrapper.cpp:95-98, :116-120); a shape below 1 is refused
 // (PolyaGammaAlt.cpp:207-210: message and 0), flagged, and left at the 0 of the zeroing launch.
 template <class P>
-__global__ __launch_bounds__(kTqBlock, 3) void k_rpg_tasks(double* __restrict__ x, const double* __restrict__ h,
+__global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double* __restrict__ x, const double* __restrict__ h,
                                                           const double* __restrict__ z, int64_t num,
                                                           int* __restrict__ iter, uint64_t seed, uint32_t epoch,
                                                           uint64_t idx0, int hybrid, int* __restrict__ status)

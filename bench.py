@@ -52,11 +52,12 @@ def parse():
     ap.add_argument("--no-mixed", action="store_true", help="skip config C3 (mixed shapes b in 1..50 through rpg_hybrid)")
     ap.add_argument("--mixed", action="store_true", help="(default now; kept so that older command lines still parse)")
     ap.add_argument("--mixed-steps", type=int, default=5)
-    ap.add_argument("--post-n", type=int, default=5000,
+    ap.add_argument("--post-n", type=int, default=10000,
                     help="rows of the problem on which a GPU chain and a CPU (oracle) chain are run on the same (X, y) and "
                          "their posterior mean/sd compared (0 = skip)")
     ap.add_argument("--post-samp", type=int, default=2000)
-    ap.add_argument("--cpu-gibbs-n", type=int, default=200_000, help="rows of the timed CPU Gibbs sample (10 sweeps)")
+    ap.add_argument("--mlogit-n", type=int, default=200_000, help="rows of the mlogit timing (P=32, J=5; 0 = skip)")
+    ap.add_argument("--cpu-gibbs-n", type=int, default=1_000_000, help="rows of the timed CPU Gibbs sample (10 sweeps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
     return ap.parse_args()
 
@@ -227,6 +228,31 @@ def cpu_hybrid(ncores, sample=2_000_000):
     t0 = time.perf_counter()
     O.rpg_hybrid(sample, h, z, 20240002, threads=ncores, literal=True)
     return sample / (time.perf_counter() - t0)
+
+
+def mlogit_bench(N, P=32, J=5, samp=20, burn=5):
+    """mlogit() as the R wrapper calls it (MultLogit.hpp:261-372): J-1 category sweeps per sweep."""
+    import bayeslogit_amd as bl
+    rng = np.random.default_rng(20240006)
+    X = rng.normal(size=(N, P)) / P ** 0.5
+    X[:, -1] = 1.0
+    B = rng.normal(size=(P, J - 1)) * 0.5
+    eta = np.concatenate([X @ B, np.zeros((N, 1))], axis=1)
+    cum = (np.exp(eta) / np.exp(eta).sum(1, keepdims=True)).cumsum(1)
+    k = (rng.uniform(size=N)[:, None] > cum).sum(1)
+    y = np.zeros((N, J - 1))
+    for j in range(J - 1):
+        y[k == j, j] = 1.0
+    m0 = np.zeros((P, J - 1))
+    P0 = np.repeat((np.eye(P) * 0.01)[:, :, None], J - 1, axis=2)
+    bl.set_seed(20240007)
+    t0 = time.perf_counter()
+    out = bl.mlogit(y, X, None, m0, P0, samp=samp, burn=burn)
+    dt = time.perf_counter() - t0
+    return {"workload": f"mlogit N={N}, P={P}, J={J}, burn {burn} + samp {samp} through the .C boundary (host upload of X, y; "
+                        "omega of every kept sweep copied back: N x (J-1) x samp doubles)",
+            "seconds": dt, "sweeps_per_s_incl_host_transfers": (samp + burn) / dt,
+            "beta_err_max_last_sweep": float(np.abs(out["beta"][-1] - B).max())}
 
 
 def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, chain=0):
@@ -473,6 +499,9 @@ def main():
     if not a.no_gibbs:
         out["gibbs"] = gibbs_bench(a.gibbs_n, a.gibbs_p, a.gibbs_sweeps, "C4", rank, world, dev, D, DistGibbs,
                                    shard_range, chain=a.gibbs_chain)
+    # mlogit through the .C boundary (host buffers in and out, omega of every sweep stored as the reference does)
+    if not a.no_gibbs and rank == 0 and world == 1 and a.mlogit_n > 0:
+        out["gibbs"]["mlogit"] = mlogit_bench(a.mlogit_n)
     # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
     if a.c5:
         out["gibbs_c5"] = gibbs_bench(12_500_000 * world, 256, a.c5_sweeps, "C5 shard", rank, world, dev, D,

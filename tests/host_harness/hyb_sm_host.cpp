@@ -15,7 +15,7 @@ void hh_alt_par(double h, double z, double* out)
 {
   int st = 0;
   const AltPar p = alt_par(h, z, alt_trunc_of(kTruncSchedule, h), st);
-  const double v[kAltParDoubles] = {p.h, p.Z, p.t, p.fz, p.lfz, p.p, p.ip, p.iq, p.R, p.ic0, p.omc, p.log_m, p.cR};
+  const double v[kAltParDoubles] = {p.h, p.Z, p.t, p.fz, p.lfz, p.p, p.R, p.ic0, p.omc, p.log_m, p.cR};
   for (int i = 0; i < kAltParDoubles; ++i) out[i] = v[i];
 }
 
@@ -23,8 +23,8 @@ void hh_sp_par(double n, double z, double* out)
 {
   int st = 0;
   const SpPar p = sp_par(n, z, &kVtab[0][0][0], st);
-  const double v[kSpParDoubles] = {p.n,  p.Z2, p.md, p.imd, p.logmd, p.lcZ, p.lhal, p.lhar, p.rl,  p.il,  p.rr,
-                                   p.ir, p.mu, p.pl, p.ipl, p.iql,   p.b,   p.mdb,  p.lmdb, p.ic0, p.omc, p.log_m};
+  const double v[kSpParDoubles] = {p.n,   p.Z2h, p.md,    p.mu,  p.pl,  p.b,   p.mdb, p.lmdb,
+                                   p.ic0, p.omc, p.log_m, p.cL0, p.cL1, p.cR0, p.cR1};
   for (int i = 0; i < kSpParDoubles; ++i) out[i] = v[i];
 }
 

@@ -296,6 +296,37 @@ def test_mlogit_matches_oracle(gpu, oracle):
     assert yc["X"].shape == (50, P) and np.all(yc["n"] == 2)
 
 
+def test_mlogit_large_many_categories(gpu, oracle):
+    """mlogit at N = 1e5 rows, J = 6 categories, binomial counts n_i in 1..3 (MultLogit.hpp:261-372): the whole chain
+    against the oracle's, omega and beta, plus the posterior moving towards the generating coefficients."""
+    import bayeslogit_amd as bl
+    rng = np.random.default_rng(19)
+    N, P, J = 100000, 12, 6
+    X = rng.normal(size=(N, P)) / 3
+    X[:, -1] = 1.0
+    B = rng.normal(size=(P, J - 1)) * 0.6
+    eta = np.concatenate([X @ B, np.zeros((N, 1))], axis=1)
+    pr = np.exp(eta) / np.exp(eta).sum(1, keepdims=True)
+    n = rng.integers(1, 4, N).astype(float)
+    cum = pr.cumsum(1)
+    cnt = np.zeros((N, J))
+    for rep in range(3):
+        u = rng.uniform(size=N)
+        k = (u[:, None] > cum).sum(1)
+        take = rep < n
+        np.add.at(cnt, (np.nonzero(take)[0], k[take]), 1.0)
+    y = cnt[:, :J - 1] / n[:, None]
+    m0 = np.zeros((P, J - 1))
+    P0 = np.repeat((np.eye(P) * 0.05)[:, :, None], J - 1, axis=2)
+    bl.set_seed(99)
+    out = bl.mlogit(y, X, n, m0, P0, samp=3, burn=3)
+    assert out["w"].shape == (3, N, J - 1) and out["beta"].shape == (3, P, J - 1)
+    wo, bo = oracle.mult_gibbs(y, X, n, m0, P0, 3, 3, oracle.chain_key(99, 0))
+    assert np.allclose(out["beta"], bo, rtol=1e-7, atol=1e-8), np.abs(out["beta"] - bo).max()
+    assert np.mean(np.isclose(out["w"], wo, rtol=1e-6, atol=0)) > 1 - 1e-5
+    assert np.abs(out["beta"][-1] - B).max() < 0.25          # six sweeps in, N/P ~ 8000: already near the truth
+
+
 @pytest.mark.parametrize("constrain", [0, 1])
 def test_streamed_thinned_and_reduced_outputs(gpu, constrain):
     """bl_gibbs_run_stream against bl_gibbs_run on the same seed: omega streamed to the host

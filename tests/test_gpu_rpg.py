@@ -173,8 +173,8 @@ def test_edge_cases(gpu, oracle):
         assert xg[0] == 0 and xg[2] == 0 and xg[3] == 0 and xg[1] > 0 and xg[4] > 0
         ref = oracle.rpg_alt(5, href, 1.0, 4) if fn is D.rpg_alt else oracle.rpg_sp(5, href, 1.0, 4)[0]
         agree(xg, ref)
-    # task-queue chunk boundaries (1024 observations per wave chunk, 64 tasks per set-up batch), z = NaN
-    for n in (63, 64, 65, 1023, 1024, 1025, 5000):
+    # task-queue chunk boundaries (512 observations per wave chunk, 64 tasks per set-up batch)
+    for n in (63, 64, 65, 511, 512, 513, 2049, 5000):
         hh = rng_h = np.random.default_rng(n).integers(3, 51, n).astype(float)
         zz = np.random.default_rng(n + 1).normal(0, 1.5, n)
         x = D.rpg_hybrid(dev_t(hh, gpu), dev_t(zz, gpu), seed=10, idx0=7)
