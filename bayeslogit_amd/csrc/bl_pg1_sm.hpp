@@ -127,8 +127,9 @@ BL_HD double pg1_a(int n, double x, double logx)
 }
 
 // The alternating series from term 1 on, literal arithmetic of PolyaGamma.cpp:175-199.
-// Returns true if the proposal X is accepted.
-BL_HD_COLD bool pg1_series(double X, double u, int& status)
+// Returns 1 if the proposal X is accepted, 0 if not; bit 1 set: the iteration cap was hit (by value: a reference
+// parameter of an out-of-line call would live in scratch).
+BL_HD_COLD int pg1_series(double X, double u)
 {
   const double logx = log(X);
   double S = pg1_a(0, X, logx);
@@ -136,14 +137,13 @@ BL_HD_COLD bool pg1_series(double X, double u, int& status)
   for (int n = 1; n < 100000; ++n) {
     if (n & 1) {
       S = S - pg1_a(n, X, logx);
-      if (Y <= S) return true;
+      if (Y <= S) return 1;
     } else {
       S = S + pg1_a(n, X, logx);
-      if (Y > S) return false;
+      if (Y > S) return 0;
     }
   }
-  status |= 1;   // iteration cap (the reference loop is uncapped)
-  return true;
+  return 3;      // iteration cap (the reference loop is uncapped): accept and flag
 }
 
 // true if any lane of the wavefront has `need` set (host build: the one caller)
@@ -175,7 +175,11 @@ BL_HD bool pg1_decide(Pg1Lane& s, double X, double A, double rarg, double u2, in
     const double r3 = 3.0 * (FAST ? bl_exp(rarg) : exp(rarg));
     if (!ok) {
       ok = u2 <= A * (1.0 - r3);
-      if (!ok) ok = pg1_series(X, u2 / A, status);                               // rare
+      if (!ok) {                                                                 // rare
+        const int r = pg1_series(X, u2 / A);
+        ok = (r & 1) != 0;
+        status |= r >> 1;
+      }
     }
   }
   s.fresh = true;                    // accepted: next draw; rejected: new proposal, :167

@@ -29,10 +29,16 @@ constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride
 //            queue drains once per launch, not once per chunk.
 // The stream belongs to the observation, so which lane draws it, and when, does not change the
 // result.
-constexpr int kChunk = 512;
+// This file is built with machine-LICM off (bayeslogit_amd/build.py): hoisting the attempt body's fp64 polynomial
+// constants out of the queue loop held 168 / 256 registers per lane (3 / 2 waves per SIMD); without it the two
+// kernels take 68 / 78, and six workgroups per CU are resident (LDS: 22.5 KB per workgroup at 256-observation
+// chunks).  Measured on C2: 2.39 -> 2.16 ms per 1e8 draws (chunk 512 at 3 per CU: 2.33; 256 at 5 / 6 / 7: 2.24 / 2.17 /
+// 2.18; 128 at 8, registers capped at 64: 2.83).
+constexpr int kChunk = 256;                          // observations per wave per chunk
+constexpr int kDevOcc1 = 6, kDevOcc2 = 6;            // resident workgroups per CU of the two class launches
 
 template <int CLS>
-__global__ __launch_bounds__(kBlock, CLS == 1 ? 3 : 2) void k_rpg_devroye(double* __restrict__ x,
+__global__ __launch_bounds__(kBlock, CLS == 1 ? kDevOcc1 : kDevOcc2) void k_rpg_devroye(double* __restrict__ x,
                                                                           const int* __restrict__ nvec, int nscalar,
                                                                           const double* __restrict__ z, int64_t num,
                                                                           uint64_t seed, uint32_t epoch, uint64_t idx0,
@@ -327,9 +333,9 @@ int bl_rpg_devroye_dev(double* x, const int* n_vec, int n_scalar, const double* 
   hipStream_t s = (hipStream_t)stream;
   // one launch per sampler class, each sized to its resident grid (3 resp. 2 workgroups per CU)
   const int64_t wg_chunks = (num + 4 * kChunk - 1) / (4 * kChunk);
-  hipLaunchKernelGGL(k_rpg_devroye<1>, dim3(blh::grid_for(wg_chunks, 1, 256 * 3)), dim3(kBlock), 0, s, x, n_vec,
+  hipLaunchKernelGGL(k_rpg_devroye<1>, dim3(blh::grid_for(wg_chunks, 1, 256 * kDevOcc1)), dim3(kBlock), 0, s, x, n_vec,
                      n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
-  hipLaunchKernelGGL(k_rpg_devroye<2>, dim3(blh::grid_for(wg_chunks, 1, 256 * 2)), dim3(kBlock), 0, s, x, n_vec,
+  hipLaunchKernelGGL(k_rpg_devroye<2>, dim3(blh::grid_for(wg_chunks, 1, 256 * kDevOcc2)), dim3(kBlock), 0, s, x, n_vec,
                      n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
   BL_HIP_TRY(hipGetLastError());
   return BL_OK;

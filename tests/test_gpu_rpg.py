@@ -180,10 +180,10 @@ def test_edge_cases(gpu, oracle):
         x = D.rpg_hybrid(dev_t(hh, gpu), dev_t(zz, gpu), seed=10, idx0=7)
         D.sync_status()
         agree(x.cpu().numpy(), oracle.rpg_hybrid(n, hh, zz, 10, 0, 7), 1e-9)
-    # chunk boundaries of the per-class work queue (512 observations per wave chunk), both classes mixed,
+    # chunk boundaries of the per-class work queue (256 observations per wave chunk), both classes mixed,
     # shapes > 1, huge |z| (proposal mass underflows to 0), z = NaN (the reference falls through with NaN)
     rng = np.random.default_rng(8)
-    for n in (511, 512, 513, 2047, 4100):
+    for n in (255, 256, 257, 511, 512, 513, 2047, 4100):
         z = rng.normal(0, 3, n)
         z[::97] = 60.0
         z[5] = np.nan
