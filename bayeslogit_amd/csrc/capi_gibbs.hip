@@ -194,6 +194,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
             st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
     if (st[7]) fprintf(stderr, "  moves redone move by move: %llu; shader clock over the sweeps: %.0f MHz\n", st[8],
                        (double)(st[10] - st[9]) / ((st[6] - st[7]) / 100.0));
+    if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups\n", st[8], st[12]);
     if (st[11]) fprintf(stderr, "  random inputs generated (waves 1-3) after %.1f us\n", (st[11] - st[0]) / 100.0);
     if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }

@@ -1,0 +1,1642 @@
+// kernels_beta.hip -- the replicated P x P stage of a Gibbs sweep on MI355X: PP = P0 + X'Omega X, Cholesky, and the beta
+// draw -- the unconstrained MVN draw (Code/C/Logit.hpp:291-320), the fork's active coordinate-wise constrained draw
+// (Logit.hpp:322-400), Normal::set_from_likelihood + draw (include/Normal.hpp:98-131) and the EM solve
+// (Logit.hpp:533-541).  One workgroup, redundantly on every rank from the (seed, sweep) stream.  gfx950 only.
+// Built with machine-LICM off (bayeslogit_amd/build.py): these are latency-bound serial routines whose cold paths
+// (erfc / inverse normal CDF of the tnorm fallback) otherwise park ~100 hoisted constants in registers and spill
+// SGPRs through v_writelane in the move loops.
+#include "bl_gibbs_kernels.hpp"
+#include "bl_pg_devroye.hpp"
+#include "bl_pg1_queue.hpp"
+#include "../../include/bayeslogit_hip.h"
+
+namespace {
+
+using namespace bl;
+
+constexpr int kBlock = 256;
+
+template <int CTRL>
+__device__ __forceinline__ double dppmov_f64(double v)      // every lane has a valid source: no `old` copy
+{
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// ================================================================ P x P stage
+#define M_(M, i, j) ((M)[(size_t)(i) + (size_t)(j) * (size_t)P])
+
+// Whole-workgroup dense routines on column-major matrices in global memory (they live in L2), right-looking, one
+// pivot per step.  Threads are a 32 x (blockDim/32) grid: the 32 run down a column (consecutive addresses), the
+// others across columns; the pivot row / column of the step is staged in LDS so that no thread walks a row of a
+// column-major matrix.  Every element receives the same updates in the same order as the textbook loops
+// (k ascending, one product subtracted per step).
+constexpr int kMaxP = 1024;
+
+// In-place A = U'U (upper triangle holds U).
+__device__ bool wg_chol_upper(double* A, int P, int* bad)
+{
+  __shared__ double srow[kMaxP];
+  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
+  for (int k = 0; k < P; ++k) {
+    const double akk = M_(A, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) M_(A, k, k) = d;
+    for (int j = k + 1 + t; j < P; j += nt) {
+      const double v = M_(A, k, j) / d;
+      M_(A, k, j) = v;
+      srow[j] = v;
+    }
+    __syncthreads();
+    for (int j = k + 1 + ty; j < P; j += ny) {
+      const double sj = srow[j];
+      for (int i = k + 1 + tx; i <= j; i += 32) M_(A, i, j) -= srow[i] * sj;
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// In-place S = L L' (lower triangle holds L; strict upper zeroed).
+__device__ bool wg_chol_lower(double* S, int P, int* bad)
+{
+  __shared__ double scol[kMaxP];
+  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
+  for (int k = 0; k < P; ++k) {
+    const double akk = M_(S, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) M_(S, k, k) = d;
+    for (int i = k + 1 + t; i < P; i += nt) {
+      const double v = M_(S, i, k) / d;
+      M_(S, i, k) = v;
+      scol[i] = v;
+    }
+    __syncthreads();
+    for (int j = k + 1 + ty; j < P; j += ny) {
+      const double sj = scol[j];
+      for (int i = j + tx; i < P; i += 32) M_(S, i, j) -= scol[i] * sj;
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < P * P; e += nt) {
+    const int i = e % P, j = e / P;
+    if (i < j) M_(S, i, j) = 0.0;
+  }
+  __syncthreads();
+  return true;
+}
+
+// B (P x nrhs, leading dim ldb) <- U'^{-1} B : forward substitution, all columns at once.  tri: B is lower
+// triangular on entry (the identity, when inverting) and stays so: column c is zero above row c and is skipped there.
+__device__ void wg_solve_Ut(const double* U, double* B, int P, int nrhs, int ldb, bool tri = false)
+{
+  __shared__ double su[kMaxP], sb[kMaxP];
+  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
+  for (int i = 0; i < P; ++i) {
+    const double d = M_(U, i, i);
+    const int cend = tri ? (i + 1 < nrhs ? i + 1 : nrhs) : nrhs;      // columns whose row i can be non-zero
+    for (int c = t; c < cend; c += nt) {
+      const double v = B[i + (size_t)c * ldb] / d;
+      B[i + (size_t)c * ldb] = v;
+      sb[c] = v;
+    }
+    for (int j = i + 1 + t; j < P; j += nt) su[j] = M_(U, i, j);
+    __syncthreads();
+    if (nrhs == 1) {
+      const double b0 = sb[0];
+      for (int j = i + 1 + t; j < P; j += nt) B[j] -= su[j] * b0;
+    } else {
+      for (int c = ty; c < cend; c += ny) {
+        const double bc = sb[c];
+        double* col = B + (size_t)c * ldb;
+        for (int j = i + 1 + tx; j < P; j += 32) col[j] -= su[j] * bc;
+      }
+    }
+    __syncthreads();
+  }
+}
+// B <- U^{-1} B : backward substitution
+__device__ void wg_solve_U(const double* U, double* B, int P, int nrhs, int ldb)
+{
+  __shared__ double su[kMaxP], sb[kMaxP];
+  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
+  for (int i = P - 1; i >= 0; --i) {
+    const double d = M_(U, i, i);
+    for (int c = t; c < nrhs; c += nt) {
+      const double v = B[i + (size_t)c * ldb] / d;
+      B[i + (size_t)c * ldb] = v;
+      sb[c] = v;
+    }
+    for (int j = t; j < i; j += nt) su[j] = M_(U, j, i);
+    __syncthreads();
+    if (nrhs == 1) {
+      const double b0 = sb[0];
+      for (int j = t; j < i; j += nt) B[j] -= su[j] * b0;
+    } else {
+      for (int c = ty; c < nrhs; c += ny) {
+        const double bc = sb[c];
+        double* col = B + (size_t)c * ldb;
+        for (int j = tx; j < i; j += 32) col[j] -= su[j] * bc;
+      }
+    }
+    __syncthreads();
+  }
+}
+// b <- L^{-1} b : forward substitution, single rhs
+__device__ void wg_solve_L(const double* L, double* b, int P)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    if (t == 0) b[i] /= M_(L, i, i);
+    __syncthreads();
+    for (int j = i + 1 + t; j < P; j += (int)blockDim.x) b[j] -= M_(L, j, i) * b[i];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+  for (int m = 32; m > 0; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+  for (int m = 32; m > 0; m >>= 1) v = fmin(v, __shfl_xor(v, m));
+  return v;
+}
+
+__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg);
+
+__global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
+{
+  extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
+  const int P = a.P, t = threadIdx.x;
+  double* A = a.work;                      // PP, then U
+  double* S = a.work + (size_t)P * P;      // PP^{-1}
+  double* mP = a.work + 2 * (size_t)P * P; // posterior mean
+  double* zz = mP + P;
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  for (int e = t; e < P * P; e += (int)blockDim.x) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
+  __syncthreads();
+  if (!wg_chol_upper(A, P, &bad)) {
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    return;
+  }
+
+  if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
+    for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
+    if (mode == blk::B_MVN && t < P) {
+      // eps_i = r.norm(0,1), i = 0..P-1 in stream order: normal i is exactly block i
+      Stream r;
+      r.init(a.seed, 0, DOM_BETA, a.epoch);
+      for (int i = t; i < P; i += (int)blockDim.x) {
+        r.blk = (uint32_t)i;
+        r.has = false;
+        zz[i] = r.norm(0.0, 1.0);
+      }
+    }
+    __syncthreads();
+    wg_solve_Ut(A, mP, P, 1, P);
+    wg_solve_U(A, mP, P, 1, P);
+    if (mode == blk::B_MVN) {
+      wg_solve_U(A, zz, P, 1, P);
+      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = zz[j] + mP[j];
+    } else {
+      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = mP[j];
+    }
+    return;
+  }
+
+  // S = PP^{-1}: two triangular solves on the identity
+  for (int e = t; e < P * P; e += (int)blockDim.x) S[e] = (e % P == e / P) ? 1.0 : 0.0;
+  __syncthreads();
+  wg_solve_Ut(A, S, P, P, P, true);
+  wg_solve_U(A, S, P, P, P);
+
+  if (mode == blk::B_FROM_LIK) {
+    // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps   (Normal.hpp:98-131)
+    for (int i = t; i < P; i += (int)blockDim.x) {
+      double s = 0.0;
+      for (int k2 = 0; k2 < P; ++k2) s += M_(S, i, k2) * a.bP[k2];
+      mP[i] = s;
+    }
+    if (t < P) {
+      Stream r;
+      r.init(a.seed, 0, DOM_BETA, a.epoch);
+      for (int i = t; i < P; i += (int)blockDim.x) {
+        r.blk = (uint32_t)i;
+        r.has = false;
+        zz[i] = r.norm(0.0, 1.0);
+      }
+    }
+    __syncthreads();
+    if (!wg_chol_lower(S, P, &bad)) {
+      __syncthreads();
+      if (t == 0) atomicOr(a.status, ST_NOT_PD);
+      return;
+    }
+    for (int i = t; i < P; i += (int)blockDim.x) {
+      double le = 0.0;
+      for (int k2 = 0; k2 <= i; ++k2) le += M_(S, i, k2) * zz[k2];
+      a.beta_out[i] = le + mP[i];
+    }
+    return;
+  }
+
+  // ---- B_CONSTRAINED: Logit.hpp:322-400 ----
+  for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
+  __syncthreads();
+  wg_solve_Ut(A, mP, P, 1, P);
+  wg_solve_U(A, mP, P, 1, P);
+  if (!wg_chol_lower(S, P, &bad)) {     // L = chol(S,'L'), in place
+    __syncthreads();
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    return;
+  }
+  if (P <= 256) {
+    // z = L^{-1}(beta_prev - mP), then the coordinate sweeps with their random input pre-generated
+    for (int j = t; j < P; j += (int)blockDim.x) zz[j] = a.beta_prev[j] - mP[j];
+    __syncthreads();
+    wg_solve_L(S, zz, P);
+    constrained_wide_prepare(a, S, A);      // U in A is dead: A takes 1/L.  k_beta_sweeps follows.
+    return;
+  }
+  // LDS layout: beta, z (P doubles each), perm (P ints), then L (P*P) when it fits.  The vectors
+  // are exchanged between lanes of the serial wave, which LDS orders and global memory does not.
+  const bool l_in_lds = (size_t)P * P * 8 <= 128 * 1024;
+  double* sbeta = lds;
+  double* sz = sbeta + P;
+  int* perm = reinterpret_cast<int*>(sz + P);
+  double* Lm = l_in_lds ? sz + P + (P + 1) / 2 + 1 : S;
+  if (l_in_lds)
+    for (int e = t; e < P * P; e += (int)blockDim.x) Lm[e] = S[e];
+  for (int j = t; j < P; j += (int)blockDim.x) {
+    zz[j] = a.beta_prev[j] - mP[j];     // z = beta_prev - mP
+    sbeta[j] = a.beta_prev[j];
+    perm[j] = j;
+  }
+  __syncthreads();
+  wg_solve_L(S, zz, P);                 // z = L^{-1} z
+  for (int j = t; j < P; j += (int)blockDim.x) sz[j] = zz[j];
+  __syncthreads();
+
+  if (t < 64) {                          // one wavefront runs the serial coordinate sweeps
+    const int lane = t;
+    Stream r;
+    r.init(a.seed, 0, DOM_BETA, a.epoch);
+    const double inf = __builtin_huge_val();
+    for (int k = 0; k < P; ++k) {
+      for (int i = 0; i < P - 1; ++i) {          // random sweep order, :375-377
+        const int j = (int)(unsigned)r.flat((double)i, (double)P);
+        if (lane == 0) {
+          const int tmp = perm[i];
+          perm[i] = perm[j];
+          perm[j] = tmp;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < P; ++i) {              // :380-398
+        const int c = perm[i];
+        const double z1 = sz[c];
+        double lo = -inf, hi = inf;
+        for (int j = c + lane; j < P - 1; j += 64) {
+          const double l1 = M_(Lm, j, c);
+          const double c1 = z1 - sbeta[j] / l1;
+          if (l1 > 0.0 && c1 > lo) lo = c1;
+          else if (l1 < 0.0 && c1 < hi) hi = c1;
+        }
+        const double cmin = wave_max(lo), cmax = wave_min(hi);
+        const double z2 = tnorm(r, cmin, cmax);
+        const double dz = z2 - z1;
+        for (int j = c + lane; j < P; j += 64) sbeta[j] += M_(Lm, j, c) * dz;
+        if (lane == 0) sz[c] = z2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = sbeta[j];
+}
+
+// ============================================= P x P stage, P <= 64: everything on chip
+// k_beta64 does the same four jobs as k_beta with the three P x P matrices in LDS (leading
+// dimension P+1: conflict-free rows and columns) and, for the constrained draw, a serial
+// coordinate loop stripped to its dependent chain:
+//   * every random input of the draw is generated BEFORE the loop, in parallel (possible
+//     because a tnorm call owns exactly nine uniforms whatever its bounds): the P-1 swap
+//     targets of each random scan and, per tnorm call, the four proposal pairs with their
+//     logs and Box-Muller normal already taken;
+//   * lane j of a wavefront owns row j (beta_j in a register, z in LDS); the moves are taken in speculative
+//     groups on all four wavefronts (see the kernel), and a move that needs its bounds gets them as a 64-lane
+//     max/min by DPP (no LDS round trip), with 1/L precomputed elementwise.
+#define L_(M, i, j) ((M)[(i) + (j) * ld])
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// raw v_max_f64 / v_min_f64 (operands are never NaN here; skips the canonicalising pre-pass
+// that fmax()/fmin() lower to)
+__device__ __forceinline__ double vmax64(double a, double b)
+{
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin64(double a, double b)
+{
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_rm(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// max of mx and min of mn over the 64 lanes, returned wave-uniform: butterfly inside each row
+// of 16 lanes (4 DPP levels), then row_bcast15 / row_bcast31 fold the four rows into row 3.
+// (A float-key fast path -- one VOP2-DPP op per level, winner located by ballot -- was tried and
+// measured slower: its VALU->SGPR->branch crossings cost more than the 64-bit moves they save.)
+__device__ __forceinline__ void wave_maxmin(double& mx, double& mn)
+{
+  mx = vmax64(mx, dppmov_f64<0xB1>(mx));  mn = vmin64(mn, dppmov_f64<0xB1>(mn));    // quad_perm [1,0,3,2]
+  mx = vmax64(mx, dppmov_f64<0x4E>(mx));  mn = vmin64(mn, dppmov_f64<0x4E>(mn));    // quad_perm [2,3,0,1]
+  mx = vmax64(mx, dppmov_f64<0x141>(mx)); mn = vmin64(mn, dppmov_f64<0x141>(mn));   // row_half_mirror
+  mx = vmax64(mx, dppmov_f64<0x140>(mx)); mn = vmin64(mn, dppmov_f64<0x140>(mn));   // row_mirror
+  mx = vmax64(mx, dpp_f64_rm<0x142, 0xa>(mx)); mn = vmin64(mn, dpp_f64_rm<0x142, 0xa>(mn));   // row_bcast15 -> rows 1,3
+  mx = vmax64(mx, dpp_f64_rm<0x143, 0xc>(mx)); mn = vmin64(mn, dpp_f64_rm<0x143, 0xc>(mn));   // row_bcast31 -> rows 2,3
+  mx = readlane_f64(mx, 63);
+  mn = readlane_f64(mn, 63);
+}
+
+// tnorm from the pre-generated record of the call, attempts evaluated by lanes 0..3 at once.
+// Lane g < 5 holds group g of the record: g < 4: (ua, log ua, log ub, Box-Muller normal) of
+// attempt g; g = 4: (fallback uniform, -, -, -).  lo/hi are wave-uniform.  The first accepted
+// attempt in attempt order wins, else the exact inverse-CDF draw: same decisions and values as
+// bl::tnorm on the same nine uniforms.
+__device__ __forceinline__ double tnorm_lanes(double r0, double r1, double r2, double r3, int lane, double lo, double hi)
+{
+  if (!(hi - lo > 0.0)) return lo;
+  double x;
+  bool ok;
+  bool flip = false;
+  double a = lo, b = hi;
+  if (lo <= 0.0 && hi >= 0.0) {
+    if (hi - lo > 2.5066282746310002) {
+      x = r3;
+      ok = x >= lo && x <= hi;
+    } else {
+      x = lo + (hi - lo) * r0;
+      ok = r2 <= -0.5 * x * x;
+    }
+  } else {
+    flip = hi < 0.0;
+    a = flip ? -hi : lo;
+    b = flip ? -lo : hi;
+    // this branch is on the dependent chain of every coordinate move: the short sqrt / divide forms
+    // (<= 1 ulp from the IEEE ones)
+    const double s4 = a * a + 4.0;
+    const double alpha = 0.5 * (a + (s4 < 1e300 ? bl_sqrt(s4) : sqrt(s4)));
+    const double ialpha = bl_div(1.0, alpha);
+    if (b - a > ialpha) {
+      x = a - r1 * ialpha;
+      const double d = x - alpha;
+      ok = x <= b && r2 <= -0.5 * d * d;
+    } else {
+      x = a + (b - a) * r0;
+      ok = r2 <= 0.5 * (a * a - x * x);
+    }
+  }
+  const uint64_t m = __ballot(ok && lane < 4);
+  if (m != 0) {
+    const int first = __builtin_ctzll(m);
+    x = readlane_f64(x, first);
+    return flip ? -x : x;
+  }
+  const double u8 = readlane_f64(r0, 4);
+  if (lo <= 0.0 && hi >= 0.0) {
+    const double pl = isinf(lo) ? 0.0 : 0.5 * erfc(-lo * kSqrtHalfR);
+    const double ph = isinf(hi) ? 1.0 : 0.5 * erfc(-hi * kSqrtHalfR);
+    double xi = qnorm(pl + u8 * (ph - pl));
+    xi = xi < lo ? lo : xi;
+    xi = xi > hi ? hi : xi;
+    return xi;
+  }
+  x = tnorm_inv_right(a, b, u8);
+  return flip ? -x : x;
+}
+
+// uniform number `ui` of stream (seed, 0, DOM_BETA, epoch)
+__device__ __forceinline__ double beta_stream_unif(uint64_t seed, uint32_t epoch, uint32_t ui)
+{
+  const U4 o = philox4x32_10(0u, ctr1_of(0, DOM_BETA), epoch, ui >> 1, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (ui & 1u) ? u52(o.z, o.w) : u52(o.x, o.y);
+}
+
+// whole-workgroup dense helpers on LDS matrices with leading dimension ld
+__device__ bool lds_chol_upper(double* A, int P, int ld, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(A, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) L_(A, k, k) = d;
+    for (int j = k + 1 + t; j < P; j += kBlock) L_(A, k, j) = L_(A, k, j) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i <= j) L_(A, i, j) -= L_(A, k, i) * L_(A, k, j);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+__device__ bool lds_chol_lower(double* S, int P, int ld, int* bad)
+{
+  const int t = threadIdx.x;
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(S, k, k);
+    if (!(akk > 0.0)) {
+      if (t == 0) *bad = 1;
+      return false;
+    }
+    const double d = sqrt(akk);
+    __syncthreads();
+    if (t == 0) L_(S, k, k) = d;
+    for (int i = k + 1 + t; i < P; i += kBlock) L_(S, i, k) = L_(S, i, k) / d;
+    __syncthreads();
+    const int m = P - k - 1;
+    for (int e = t; e < m * m; e += kBlock) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i >= j) L_(S, i, j) -= L_(S, i, k) * L_(S, j, k);
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    if (i < j) L_(S, i, j) = 0.0;
+  }
+  __syncthreads();
+  return true;
+}
+__device__ void lds_solve_Ut(const double* U, double* B, int P, int ld, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    const double d = L_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + c * ldb] /= d;
+    __syncthreads();
+    const int m = P - i - 1;
+    for (int e = t; e < m * nrhs; e += kBlock) {
+      const int j = i + 1 + e % m, c = e / m;
+      B[j + c * ldb] -= L_(U, i, j) * B[i + c * ldb];
+    }
+    __syncthreads();
+  }
+}
+__device__ void lds_solve_U(const double* U, double* B, int P, int ld, int nrhs, int ldb)
+{
+  const int t = threadIdx.x;
+  for (int i = P - 1; i >= 0; --i) {
+    const double d = L_(U, i, i);
+    for (int c = t; c < nrhs; c += kBlock) B[i + c * ldb] /= d;
+    __syncthreads();
+    for (int e = t; e < i * nrhs; e += kBlock) {
+      const int j = e % i, c = e / i;
+      B[j + c * ldb] -= L_(U, j, i) * B[i + c * ldb];
+    }
+    __syncthreads();
+  }
+}
+__device__ void lds_solve_L(const double* Lm, double* b, int P, int ld)
+{
+  const int t = threadIdx.x;
+  for (int i = 0; i < P; ++i) {
+    if (t == 0) b[i] /= L_(Lm, i, i);
+    __syncthreads();
+    for (int j = i + 1 + t; j < P; j += kBlock) b[j] -= L_(Lm, j, i) * b[i];
+    __syncthreads();
+  }
+}
+
+constexpr int kRec = 20;   // doubles per pre-generated tnorm record: 4 attempts x (ua, log ua, log ub, normal) + (u8,0,0,0)
+
+// ---- single-wavefront dense kernels on LDS matrices (P <= 64, lane = column or row) ----
+// One wave needs no s_barrier: LDS operations of a wave execute in program order, so a
+// wave-level scheduling fence between a phase's writes and the next phase's reads is enough.
+// The workgroup versions above pay two or three barriers per column (~1.4 us per column
+// measured); these leave the other three waves free to generate the draw's random input, build the scan
+// tables and solve for mP at the same time.
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+__device__ __forceinline__ double bcast_f64(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// A = U'U in place (upper triangle holds U); lane j owns column j.  Same operation order per
+// element as the reference's LAPACK-style column Cholesky (subtractions in ascending k).  The
+// pivot row is passed between lanes by readlane, so the trailing update touches LDS only for the
+// lane's own column (independent addresses: the loads of several rows are in flight together).
+__device__ bool w_chol_upper(double* A, int P, int ld, int lane)
+{
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(A, k, k);
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    double ukj = 0.0;
+    if (lane > k && lane < P) {
+      ukj = L_(A, k, lane) / d;
+      L_(A, k, lane) = ukj;
+    }
+    if (lane == k) L_(A, k, k) = d;
+    double* col = A + lane * ld;
+    int i = k + 1;
+    for (; i + 3 < P; i += 4) {
+      const double u0 = bcast_f64(ukj, i), u1 = bcast_f64(ukj, i + 1), u2 = bcast_f64(ukj, i + 2), u3 = bcast_f64(ukj, i + 3);
+      if (lane < P) {
+        const double a0 = col[i], a1 = col[i + 1], a2 = col[i + 2], a3 = col[i + 3];
+        if (lane >= i) col[i] = a0 - u0 * ukj;
+        if (lane >= i + 1) col[i + 1] = a1 - u1 * ukj;
+        if (lane >= i + 2) col[i + 2] = a2 - u2 * ukj;
+        if (lane >= i + 3) col[i + 3] = a3 - u3 * ukj;
+      }
+    }
+    for (; i < P; ++i) {
+      const double u0 = bcast_f64(ukj, i);
+      if (lane >= i && lane < P) col[i] -= u0 * ukj;
+    }
+    WAVE_SYNC();
+  }
+  return true;
+}
+
+// S = L L' in place (lower triangle holds L, strict upper zeroed); lane i owns row i.
+__device__ bool w_chol_lower(double* S, int P, int ld, int lane)
+{
+  for (int k = 0; k < P; ++k) {
+    const double akk = L_(S, k, k);
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    double lik = 0.0;
+    if (lane > k && lane < P) {
+      lik = L_(S, lane, k) / d;
+      L_(S, lane, k) = lik;
+    }
+    if (lane == k) L_(S, k, k) = d;
+    int j = k + 1;
+    for (; j + 3 < P; j += 4) {
+      const double l0 = bcast_f64(lik, j), l1 = bcast_f64(lik, j + 1), l2 = bcast_f64(lik, j + 2), l3 = bcast_f64(lik, j + 3);
+      if (lane < P) {
+        const double a0 = L_(S, lane, j), a1 = L_(S, lane, j + 1), a2 = L_(S, lane, j + 2), a3 = L_(S, lane, j + 3);
+        if (lane >= j) L_(S, lane, j) = a0 - lik * l0;
+        if (lane >= j + 1) L_(S, lane, j + 1) = a1 - lik * l1;
+        if (lane >= j + 2) L_(S, lane, j + 2) = a2 - lik * l2;
+        if (lane >= j + 3) L_(S, lane, j + 3) = a3 - lik * l3;
+      }
+    }
+    for (; j < P; ++j) {
+      const double l0 = bcast_f64(lik, j);
+      if (lane >= j && lane < P) L_(S, lane, j) -= lik * l0;
+    }
+    WAVE_SYNC();
+  }
+  for (int j = 1; j < P; ++j)
+    if (lane < j && lane < P) L_(S, lane, j) = 0.0;
+  WAVE_SYNC();
+  return true;
+}
+
+// Register-resident Cholesky on one wavefront (P <= 64): lane i keeps row i of the (upper) triangle in 64
+// registers, so a step touches LDS only to pass the pivot row around (one 64-double buffer), not to update
+// the trailing matrix.  Same arithmetic as w_chol_upper / w_chol_lower -- u_kj = a_kj / sqrt(a_kk), then
+// a_ij -= u_ki u_kj, k ascending (a product of the same two numbers either way round) -- so the factor is
+// bit-identical; LOWER = false: A = U'U, reads and writes the upper triangle of M; LOWER = true: M = L L', reads
+// the lower triangle of M (row i of the transposed problem is column i of the lower triangle), writes L = U'
+// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS.  Measured in k_beta64: 65 us each
+// against 130 for w_chol_upper / w_chol_lower.
+template <bool LOWER>
+__device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
+{
+  double r[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const bool in = lane < P && j < P && j >= lane;
+    r[j] = in ? (LOWER ? L_(M, j, lane) : L_(M, lane, j)) : 0.0;
+  }
+  for (int k = 0; k < P; ++k) {
+    if (lane == k) {
+#pragma unroll
+      for (int j = 0; j < 64; ++j) buf[j] = r[j];
+    }
+    WAVE_SYNC();
+    const double akk = buf[k];
+    if (!(akk > 0.0)) return false;
+    const double d = sqrt(akk);
+    const double a_kl = buf[lane];
+    WAVE_SYNC();
+    double u = 0.0;
+    if (lane > k && lane < P) u = a_kl / d;
+    if (lane >= k && lane < P) {
+      const double v = lane == k ? d : u;
+      if (LOWER) L_(M, lane, k) = v;
+      else L_(M, k, lane) = v;
+    }
+    buf[lane] = u;                                 // u_kj for j > k, 0 for j <= k and outside the matrix
+    WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < 64; ++j) r[j] = fma(-u, buf[j], r[j]);     // rows i <= k have u = 0: unchanged
+    WAVE_SYNC();
+  }
+  if (LOWER) {
+    for (int j = 1; j < P; ++j)
+      if (lane < j && lane < P) L_(M, lane, j) = 0.0;
+    WAVE_SYNC();
+  }
+  return true;
+}
+
+// S <- PP^{-1} given U (PP = U'U): S starts as I; lane c solves U'y = e_c then U x = y on its own
+// column of S (dot-product form, ascending k as the reference's trsm), four products in flight.
+__device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int lane)
+{
+  const int c = lane < P ? lane : 0;
+  double* col = S + c * ld;
+  for (int i = 0; i < P; ++i) {                            // forward: U' y = e_c
+    const double* ui = U + i * ld;                         // column i of U: U[k][i], k < i
+    double acc = col[i];
+    int k = 0;
+    for (; k + 3 < i; k += 4) {
+      const double p0 = ui[k] * col[k], p1 = ui[k + 1] * col[k + 1], p2 = ui[k + 2] * col[k + 2], p3 = ui[k + 3] * col[k + 3];
+      acc = (((acc - p0) - p1) - p2) - p3;
+    }
+    for (; k < i; ++k) acc -= ui[k] * col[k];
+    const double y = acc / ui[i];
+    if (lane < P) col[i] = y;
+  }
+  for (int i = P - 1; i >= 0; --i) {                       // backward: U x = y
+    double acc = col[i];
+    int k = i + 1;
+    for (; k + 3 < P; k += 4) {
+      const double p0 = L_(U, i, k) * col[k], p1 = L_(U, i, k + 1) * col[k + 1], p2 = L_(U, i, k + 2) * col[k + 2],
+                   p3 = L_(U, i, k + 3) * col[k + 3];
+      acc = (((acc - p0) - p1) - p2) - p3;
+    }
+    for (; k < P; ++k) acc -= L_(U, i, k) * col[k];
+    const double x = acc / L_(U, i, i);
+    if (lane < P) col[i] = x;
+  }
+  WAVE_SYNC();
+}
+
+// b <- U'^{-1} b, b_j in lane j's register
+__device__ double w_solve_Ut_vec(const double* U, double b, int P, int ld, int lane)
+{
+  for (int i = 0; i < P; ++i) {
+    const double bi = bcast_f64(b, i) / L_(U, i, i);
+    if (lane == i) b = bi;
+    if (lane > i && lane < P) b -= L_(U, i, lane) * bi;
+  }
+  return b;
+}
+// b <- U^{-1} b
+__device__ double w_solve_U_vec(const double* U, double b, int P, int ld, int lane)
+{
+  for (int i = P - 1; i >= 0; --i) {
+    const double bi = bcast_f64(b, i) / L_(U, i, i);
+    if (lane == i) b = bi;
+    if (lane < i) b -= L_(U, lane, i) * bi;
+  }
+  return b;
+}
+// b <- L^{-1} b (L lower)
+__device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int lane)
+{
+  for (int i = 0; i < P; ++i) {
+    const double bi = bcast_f64(b, i) / L_(Lm, i, i);
+    if (lane == i) b = bi;
+    if (lane > i && lane < P) b -= L_(Lm, lane, i) * bi;
+  }
+  return b;
+}
+
+// One speculative group of the constrained sweeps (see k_beta64): beta after each of the group's moves on the
+// fast path (bs_out: after all of them) and the bound test of moves 2W and 2W+1 of the group.  Returns true if
+// both pass in every lane.
+template <int W, int G>
+__device__ __forceinline__ bool spec_group(const double* S, const double* Ri, const double* A, int ld, int lane, int i0,
+                                           int cvec, double svec, double z1v, double dzv, double bj, double& bs_out)
+{
+  constexpr int M = G / 4, u0 = W * M;          // this wavefront tests moves u0 .. u0 + M - 1 of the group
+  double lg[G];
+#pragma unroll
+  for (int u = 0; u < G; ++u) lg[u] = L_(S, lane, __builtin_amdgcn_readlane(cvec, i0 + u));
+  double rl[M], rh[M], sm[M], zm[M], bm[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int c = __builtin_amdgcn_readlane(cvec, i0 + u0 + m);
+    rl[m] = L_(Ri, lane, c);
+    rh[m] = L_(A, lane, c);
+    sm[m] = readlane_f64(svec, i0 + u0 + m);
+    zm[m] = readlane_f64(z1v, i0 + u0 + m);
+    bm[m] = bj;
+  }
+  double bs = bj;
+#pragma unroll
+  for (int u = 0; u < G; ++u) {
+    if (u >= u0 && u < u0 + M) bm[u - u0] = bs;
+    bs += lg[u] * readlane_f64(dzv, i0 + u);
+  }
+  bs_out = bs;
+  uint64_t acc = 0ull;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double lo = zm[m] - bm[m] * rl[m], hi = zm[m] - bm[m] * rh[m];   // NaN: the row does not bound that side
+    // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit; 2: ogt, 4: olt
+    acc |= __builtin_amdgcn_fcmp(lo, sm[m], 2) | __builtin_amdgcn_fcmp(hi, sm[m], 4) |
+           __builtin_amdgcn_fcmp(lo, -1.26, 2) | __builtin_amdgcn_fcmp(hi, 1.26, 4);
+  }
+  return acc == 0ull;
+}
+template <int G>
+__device__ __forceinline__ bool spec_group_w(int wave, const double* S, const double* Ri, const double* A, int ld, int lane,
+                                             int i0, int cvec, double svec, double z1v, double dzv, double bj,
+                                             double& bs_out)
+{
+  switch (wave) {
+    case 0: return spec_group<0, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    case 1: return spec_group<1, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    case 2: return spec_group<2, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+    default: return spec_group<3, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
+{
+  extern __shared__ double lds[];
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
+  const int P = a.P, t = threadIdx.x, ld = P + 1;
+  double* A = lds;                       // PP -> U
+  double* S = A + P * ld;                // PP^{-1} -> L
+  double* Ri = S + P * ld;               // 1/L elementwise (constrained mode)
+  double* mP = Ri + P * ld;
+  double* zz = mP + P;
+  int* perm = reinterpret_cast<int*>(zz + P);       // P ints
+  int* ptab = perm + P + (P & 1);                    // ptab[k][i]: coordinate visited at step i of scan k (P*P ints)
+  double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
+  double* rec = a.work;                             // P*P records of kRec doubles
+  __shared__ int bad;
+  __shared__ int uflag;                              // 0: U not ready; 1: U = chol(PP) is in A; 2: PP not positive definite
+  if (t == 0) bad = 0;
+  if (t == 0) uflag = 0;
+  if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
+  const bool need_inverse = mode == blk::B_CONSTRAINED || mode == blk::B_FROM_LIK;
+  for (int e = t; e < P * P; e += kBlock) {
+    const int i = e % P, j = e / P;
+    L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
+    if (need_inverse) L_(S, i, j) = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+
+  if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
+    // nothing to overlap with: the whole workgroup factors and solves (measured 0.136 ms vs 0.161 ms
+    // for the single-wave routines below)
+    if (!lds_chol_upper(A, P, ld, &bad)) {
+      __syncthreads();
+      if (t == 0) atomicOr(a.status, ST_NOT_PD);
+      return;
+    }
+    for (int j = t; j < P; j += kBlock) mP[j] = a.bP[j];
+    if (mode == blk::B_MVN)
+      for (int i = t; i < P; i += kBlock) {
+        // eps_i = r.norm(0,1) in stream order: normal i is exactly Philox block i     (Logit.hpp:311)
+        const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * i), u2 = beta_stream_unif(a.seed, a.epoch, 2 * i + 1);
+        zz[i] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+      }
+    __syncthreads();
+    lds_solve_Ut(A, mP, P, ld, 1, P);
+    lds_solve_U(A, mP, P, ld, 1, P);
+    if (mode == blk::B_MVN) {
+      lds_solve_U(A, zz, P, ld, 1, P);
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = zz[j] + mP[j];
+    } else {
+      for (int j = t; j < P; j += kBlock) a.beta_out[j] = mP[j];
+    }
+    return;
+  }
+
+  if (t < 64) {
+    // ================= wave 0: the dense stage, alone, no workgroup barriers =================
+    const int lane = t;
+    bool ok = w_chol_reg<false>(A, P, ld, lane, recL);                        // U = chol(PP,'U') (recL is idle until the sweeps)
+    // wave 1 solves for mP from U once its own work is done (it idles otherwise): hand U over
+    __threadfence_block();
+    if (lane == 0) __hip_atomic_store(&uflag, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
+    if (ok && need_inverse) {
+      w_inverse_from_U(A, S, P, ld, lane);                                     // S = PP^{-1}
+      if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
+      if (mode == blk::B_FROM_LIK) {
+        // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps               (Normal.hpp:98-131)
+        double mean = 0.0, e = 0.0;
+        if (lane < P) {
+          for (int k2 = 0; k2 < P; ++k2) mean += L_(S, lane, k2) * a.bP[k2];
+          const double u1 = beta_stream_unif(a.seed, a.epoch, 2 * lane), u2 = beta_stream_unif(a.seed, a.epoch, 2 * lane + 1);
+          e = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+          zz[lane] = e;
+        }
+        WAVE_SYNC();
+        ok = w_chol_lower(S, P, ld, lane);
+        if (ok && lane < P) {
+          double le = 0.0;
+          for (int k2 = 0; k2 <= lane; ++k2) le += L_(S, lane, k2) * zz[k2];
+          a.beta_out[lane] = le + mean;
+        }
+      } else {
+        // B_CONSTRAINED set-up, Logit.hpp:335-366 (mP: wave 1; z: after the barrier, when mP is there)
+        if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
+        ok = w_chol_reg<true>(S, P, ld, lane, recL);                          // L = chol(S,'L')
+        if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
+      }
+    }
+    if (!ok && t == 0) bad = 1;
+  } else if (mode == blk::B_CONSTRAINED) {
+    // ====== waves 1-3, meanwhile: every random input of the draw, in stream order
+    // (per scan k, P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms) ======
+    const int tt = t - 64;
+    const uint32_t per_scan = (uint32_t)(10 * P - 1);
+    // the tnorm records: waves 2-3 take the first 25/32 of them, wave 1 the rest once the scan tables are built
+    const int nsplit = (P * P * 25) / 32;
+    auto records = [&](int e0, int e1, int first, int stride) {
+      for (int e = e0 + first; e < e1; e += stride) {
+        const int k = e / P, i = e % P;
+        const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+        double* R = rec + (size_t)e * kRec;
+        for (int m = 0; m < 4; ++m) {
+          const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+          const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+          const double lua = log(ua);
+          R[4 * m] = ua;
+          R[4 * m + 1] = lua;
+          R[4 * m + 2] = log(ub);
+          R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+        }
+        R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+        R[17] = R[18] = R[19] = 0.0;
+      }
+    };
+    if (tt < 64) {
+      // wave 1: the scan tables.  Scan k's P-1 swaps (r.flat(i, P), Logit.hpp:375-377) applied to the identity,
+      // all scans in parallel (lane k, its row of ptab as scratch), then composed in scan order: `is` persists
+      // across scans (Logit.hpp:368-377); the composition is in place, row by row.  One wavefront: no
+      // workgroup barrier, wave 0 is in the dense stage.
+      if (tt < P) {
+        int* sg = ptab + tt * P;
+        for (int i = 0; i < P; ++i) sg[i] = i;
+        for (int i = 0; i < P - 1; ++i) {
+          const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)tt * per_scan + (uint32_t)i);
+          const int j = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P)
+          const int tmp = sg[i];
+          sg[i] = sg[j];
+          sg[j] = tmp;
+        }
+      }
+      WAVE_SYNC();
+      for (int k = 1; k < P; ++k) {
+        int v = 0;
+        if (tt < P) v = ptab[(k - 1) * P + ptab[k * P + tt]];
+        WAVE_SYNC();
+        if (tt < P) ptab[k * P + tt] = v;
+        WAVE_SYNC();
+      }
+      records(nsplit, P * P, tt, 64);
+      // mP = U^{-1} U^{-T} bP (Logit.hpp:335-340), as soon as wave 0 has published U (long since, normally)
+      int f;
+      do {
+        f = __hip_atomic_load(&uflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!f) __builtin_amdgcn_s_sleep(8);
+      } while (!f);
+      if (f == 1) {
+        double m = tt < P ? a.bP[tt] : 0.0;
+        m = w_solve_Ut_vec(A, m, P, ld, tt);
+        m = w_solve_U_vec(A, m, P, ld, tt);
+        if (tt < P) mP[tt] = m;
+      }
+    } else {
+      records(0, nsplit, tt - 64, kBlock - 128);
+    }
+    // the records are read back (staged into LDS) by every wave after the barrier below
+    __threadfence_block();
+    if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
+  }
+  if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
+  __syncthreads();
+  if (bad) {
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    return;
+  }
+  if (mode != blk::B_CONSTRAINED) return;
+
+  // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0, A (U is
+  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3; wave 0
+  // solves for z meanwhile.
+  for (int e = t - 64; e >= 0 && e < P * P; e += kBlock - 64) {
+    const int i = e % P, j = e / P;
+    const double l = L_(S, i, j), r = 1.0 / l;
+    const double nan = __builtin_nan("");
+    L_(Ri, i, j) = (l > 0.0 && i < P - 1) ? r : nan;
+    L_(A, i, j) = (l < 0.0 && i < P - 1) ? r : nan;
+  }
+  if (t < 64) {
+    double z = t < P ? a.beta_prev[t] - mP[t] : 0.0;                         // z = L^{-1}(beta_prev - mP)
+    z = w_solve_L_vec(S, z, P, ld, t);
+    if (t < P) zz[t] = z;
+  }
+  __syncthreads();                                 // 1/L complete
+
+  if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
+  if (a.dbg && t == 0) a.dbg[9] = clock64();
+  // The coordinate sweeps: a move reads only LDS and registers (the next scan's random records travel from
+  // global scratch to LDS while a scan runs: loaded into registers at its start, stored at its end).
+  //
+  // Fast path.  A move's value is almost always the Box-Muller normal s of its first attempt: the bounds
+  // contain 0, are wider than sqrt(2 pi), and s falls inside (tnorm_lanes' first branch, attempt 0).  That
+  // is decided WITHOUT reducing the bounds: if every lane's lower candidate is <= min(s, -a) and every upper
+  // candidate >= max(s, b) for some a, b >= 0 with a + b > sqrt(2 pi), then lo <= 0 <= hi, hi - lo > sqrt(2 pi)
+  // and lo <= s <= hi -- three __ballot tests ((a, b) = (1.26, 1.26), (0, 2.51), (2.51, 0): one-sided bounds,
+  // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
+  // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
+  //
+  // Speculative groups on four wavefronts.  Moves are taken 16 (or 8) at a time on the fast path: every
+  // move of the group is assumed to take attempt 0's normal s (which is what a move whose bounds contain 0,
+  // are wider than sqrt(2 pi) and contain s does).  A group is straight-line code: its loads and broadcasts
+  // first, one dependent FMA per move (beta after u moves), and a move's test -- every lane's lower
+  // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests above --
+  // only ORs compare masks into a scalar.  One wavefront issues an instruction every ~8 cycles here, so the
+  // FOUR wavefronts of the workgroup (one per SIMD) each keep a replica of beta (lane j = row j), all run
+  // the one-FMA-per-move chain, and each tests a quarter of the group's moves; the verdicts meet in LDS at one
+  // barrier per group.  A group with a failing move (a few per draw on C4) is redone move by move with all
+  // three tests and the full tnorm, by every wavefront alike (same inputs, same arithmetic: the replicas
+  // stay identical without another exchange).  Same values as the move-by-move loop either way.
+  // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
+  // moves are gathered at its start (z1v) and a group's new values are scattered at its end.
+  const int lane = t & 63, wave = t >> 6;
+  const bool row = lane < P;
+  double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
+  const double inf = __builtin_huge_val();
+  const int nrec = P * kRec;
+  __shared__ int gflag[2][4];
+  for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
+  __syncthreads();
+  bool spec_on = true;
+  int gmax = 32;                                   // largest group of the scan
+  unsigned gi = 0;                                 // speculative groups so far (flag slot parity)
+  for (int k = 0; k < P; ++k) {
+    const double* Rk = recL + (k & 1) * nrec;
+    // next scan's records: global -> registers now, -> LDS at the end of this scan
+    constexpr int kStage = (64 * kRec + kBlock - 1) / kBlock;      // P <= 64
+    double stage[kStage];
+    if (k + 1 < P) {
+      const double* src = rec + (size_t)(k + 1) * nrec;
+#pragma unroll
+      for (int q = 0; q < kStage; ++q) {
+        const int e = t + q * kBlock;
+        stage[q] = e < nrec ? src[e] : 0.0;
+      }
+    }
+    const int g4 = (lane < 5 ? lane : 0) * 4;
+    const double qnan = __builtin_nan("");
+    const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
+    const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
+    const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
+    const double dzv = svec - z1v;
+    int nfail = 0;                                                 // moves redone move by move in this scan
+    for (int i0 = 0; i0 < P;) {
+      const int left = P - i0;
+      // groups of 32, 16 or 8 moves (a quarter of them tested by each wavefront); a shorter tail goes move by move
+      const int ng = !spec_on ? (left < 8 ? left : 8) : (left >= 32 && gmax >= 32) ? 32 : (left >= 16 && gmax >= 16) ? 16 : left >= 8 ? 8 : left;
+      const bool spec = spec_on && ng >= 8;
+      double bs = bj;
+      bool all_ok = false;
+      if (spec) {
+        bool ok_l = true;
+        if (row) {
+          if (ng == 32)
+            ok_l = spec_group_w<32>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
+          else if (ng == 16)
+            ok_l = spec_group_w<16>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
+          else
+            ok_l = spec_group_w<8>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
+        }
+        const bool okw = __ballot(!ok_l) == 0ull;                  // this wavefront's moves
+        if (lane == 0) gflag[gi & 1][wave] = okw ? 0 : 1;
+        __syncthreads();
+        const int* gf = gflag[gi & 1];
+        all_ok = __builtin_amdgcn_readfirstlane(gf[0] | gf[1] | gf[2] | gf[3]) == 0;
+        ++gi;
+      }
+      if (all_ok) {
+        bj = bs;
+        if (wave == 0 && row && lane >= i0 && lane < i0 + ng) zz[cvec] = svec;
+        i0 += ng;
+        continue;
+      }
+      nfail += ng;
+      const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
+      for (int i = i0; i < i0 + ng; ++i) {
+        const int c = __builtin_amdgcn_readlane(cvec, i);
+        const double l1 = row ? L_(S, lr, c) : 0.0, rl = row ? L_(Ri, lr, c) : qnan, rh = row ? L_(A, lr, c) : qnan;
+        const double* Rn = Rk + i * kRec + g4;
+        const double r0 = Rn[0], r1 = Rn[1], r2 = Rn[2], r3 = Rn[3];
+        const double z1 = readlane_f64(z1v, i);
+        double lo = z1 - bj * rl;                                    // NaN: this row does not bound the move from below
+        double hi = z1 - bj * rh;
+        const double s = readlane_f64(r3, 0);                        // attempt 0's normal
+        const double l0 = s < 0.0 ? s : 0.0, h0 = s > 0.0 ? s : 0.0;
+        const double l1s = s < -1.26 ? s : -1.26, h1s = s > 1.26 ? s : 1.26;
+        const double l2s = s < -2.51 ? s : -2.51, h2s = s > 2.51 ? s : 2.51;
+        double z2 = s;
+        if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0 || hi < h2s) == 0ull ||
+              __ballot(lo > l2s || hi < h0) == 0ull)) {
+          wave_maxmin(lo, hi);           // v_max_f64 / v_min_f64 return the other operand for a NaN
+          lo = lo == lo ? lo : -inf;
+          hi = hi == hi ? hi : inf;
+          z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+        }
+        const double dz = z2 - z1;
+        bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
+        if (wave == 0 && lane == 0) zz[c] = z2;
+      }
+      i0 += ng;
+    }
+    // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
+    spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
+    gmax = nfail == 0 ? 32 : 8;                                    // failures come in runs (a coordinate at its bound): small groups then
+    if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
+    if (k + 1 < P) {
+      double* Rn = recL + ((k + 1) & 1) * nrec;
+#pragma unroll
+      for (int q = 0; q < kStage; ++q) {
+        const int e = t + q * kBlock;
+        if (e < nrec) Rn[e] = stage[q];
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && row) a.beta_out[lane] = bj;
+  if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
+  if (a.dbg && t == 0) a.dbg[10] = clock64();
+}
+
+// ---- constrained coordinate sweeps for 64 < P <= 256 (Logit.hpp:368-399), same design as k_beta64's:
+// every random input generated up front by the whole workgroup (a tnorm call owns nine uniforms whatever
+// its bounds), the P^2 moves on ONE wavefront, lane l owning rows l + 64 r (beta in registers), bounds by a
+// per-lane fold then the DPP max/min, the four tnorm attempts on lanes 0-3.  L stays in global memory
+// (512 KB at P = 256: it lives in L2) next to its elementwise reciprocal; the columns of a move are fetched two
+// moves ahead, the records of the next scan are staged into LDS by the idle waves.
+// Scratch layout in a.work after the generic stage's 2 P^2 + 2 P doubles: records, then swap targets.
+__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg)
+{
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);
+  const uint32_t per_scan = (uint32_t)(10 * P - 1);
+  for (int e = t; e < P * (P - 1); e += nthr) {
+    const int k = e / (P - 1), i = e % (P - 1);
+    const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)k * per_scan + (uint32_t)i);
+    swp[e] = (int)(unsigned)((double)i + ((double)P - (double)i) * u);       // r.flat(i, P), Logit.hpp:375
+  }
+  for (int e = t; e < P * P; e += nthr) {
+    const int k = e / P, i = e % P;
+    const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+    double* R = rec + (size_t)e * kRec;
+    for (int m = 0; m < 4; ++m) {
+      const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+      const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+      const double lua = log(ua);
+      R[4 * m] = ua;
+      R[4 * m + 1] = lua;
+      R[4 * m + 2] = log(ub);
+      R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+    }
+    R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+    R[17] = R[18] = R[19] = 0.0;
+  }
+  // 1/L elementwise, off the serial loop, split by the sign test of Logit.hpp:384-391: Rlo holds 1/L where
+  // L > 0 (those rows bound the move from below), Rhi where L < 0, NaN elsewhere -- above the diagonal
+  // (L = 0: rows j < c are outside the loop of :383) and in row P-1 (the loop stops at P-2).  v_max_f64 /
+  // v_min_f64 return the other operand for a NaN, so the sweeps need no compares or selects.
+  double* Rhi = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;
+  const double nan = __builtin_nan("");
+  for (int e = t; e < P * P; e += nthr) {
+    const int j = e % P;
+    const double l = Lg[e];
+    const double r = 1.0 / l;
+    Rg[e] = (l > 0.0 && j < P - 1) ? r : nan;
+    Rhi[e] = (l < 0.0 && j < P - 1) ? r : nan;
+  }
+}
+
+// The sweeps themselves: one 4-wave workgroup (512 registers per lane available: the pipeline's register
+// sets do not spill), launched behind k_beta on the same stream.  Reads L, 1/L, z from k_beta's scratch.
+template <int RPL>
+__global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
+{
+  extern __shared__ double lds[];
+  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  if (*a.status & ST_NOT_PD) return;
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const int nrec = P * kRec;
+  const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
+  const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
+  const double* zz = a.work + 2 * (size_t)P * P + P;               // z
+  double* recL = lds;                                  // 2 x (P records): the scan in progress / next
+  double* sz = recL + 2 * nrec;                        // z
+  unsigned char* ptab = reinterpret_cast<unsigned char*>(sz + P);   // ptab[k][i]: coordinate of move i of scan k
+  double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);
+  const double* __restrict__ Rh = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;   // 1/L where L < 0, else NaN
+  for (int j = t; j < P; j += nthr) sz[j] = zz[j];
+  __syncthreads();
+  // scan permutations: each scan's swaps on the identity (thread k), then composed in scan order
+  if (t < P) {
+    unsigned char* sg = ptab + t * P;
+    for (int i = 0; i < P; ++i) sg[i] = (unsigned char)i;
+    for (int i = 0; i < P - 1; ++i) {
+      const int j = swp[t * (P - 1) + i];
+      const unsigned char tmp = sg[i];
+      sg[i] = sg[j];
+      sg[j] = tmp;
+    }
+  }
+  __syncthreads();
+  for (int k = 1; k < P; ++k) {
+    int v = 0;
+    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
+    __syncthreads();
+    if (t < P) ptab[k * P + t] = (unsigned char)v;
+    __syncthreads();
+  }
+
+  const int lane = t & 63;
+  const bool serial = t < 64;
+  const double inf = __builtin_huge_val();
+  double bj[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int j = lane + 64 * r;
+    bj[r] = (serial && j < P) ? a.beta_prev[j] : 0.0;
+  }
+  for (int e = t; e < nrec; e += nthr) recL[e] = rec[e];
+  __syncthreads();
+  for (int k = 0; k < P; ++k) {
+    const double* Rk = recL + (k & 1) * nrec;
+    if (!serial) {
+      if (k + 1 < P) {
+        double* Rn = recL + ((k + 1) & 1) * nrec;
+        const double* src = rec + (size_t)(k + 1) * nrec;
+        for (int e = t - 64; e < nrec; e += nthr - 64) Rn[e] = src[e];
+      }
+    } else {
+      const int g4 = (lane < 5 ? lane : 0) * 4;
+      const unsigned char* pk = ptab + k * P;
+      // software pipeline, kDepth register sets used round-robin (no copies: a copy would wait on the
+      // load): the columns of L and 1/L of move i + kDepth are requested as soon as move i has used its
+      // set; z and the record come from LDS one move ahead
+      constexpr int kDepth = 4;
+      double lq[kDepth][RPL], rlo[kDepth][RPL], rhi[kDepth][RPL];
+      int jr[RPL];           // this lane's rows, clamped to P-1 (a clamped row sees NaN reciprocals: no effect)
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) jr[r] = (lane + 64 * r) < P ? lane + 64 * r : P - 1;
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        const size_t co = (size_t)__builtin_amdgcn_readfirstlane((int)pk[u < P ? u : P - 1]) * P;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          lq[u][r] = (Lg + co)[jr[r]];
+          rlo[u][r] = (Rg + co)[jr[r]];
+          rhi[u][r] = (Rh + co)[jr[r]];
+        }
+      }
+      int c_n = pk[0];
+      double z1_n = sz[c_n];
+      double q0 = Rk[g4], q1 = Rk[g4 + 1], q2 = Rk[g4 + 2], q3 = Rk[g4 + 3];
+      for (int i0 = 0; i0 < P; i0 += kDepth) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+          const int i = i0 + u;
+          if (i < P) {
+            const int c = __builtin_amdgcn_readfirstlane(c_n);
+            const double r0 = q0, r1 = q1, r2 = q2, r3 = q3;
+            double l1[RPL], rl[RPL], rh[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+              l1[r] = lq[u][r];
+              rl[r] = rlo[u][r];
+              rh[r] = rhi[u][r];
+            }
+            if (i + kDepth < P) {
+              const size_t co = (size_t)__builtin_amdgcn_readfirstlane((int)pk[i + kDepth]) * P;
+#pragma unroll
+              for (int r = 0; r < RPL; ++r) {
+                lq[u][r] = (Lg + co)[jr[r]];
+                rlo[u][r] = (Rg + co)[jr[r]];
+                rhi[u][r] = (Rh + co)[jr[r]];
+              }
+            }
+            if (i + 1 < P) {
+              c_n = pk[i + 1];
+              const double* Rn = Rk + (i + 1) * kRec + g4;
+              q0 = Rn[0];
+              q1 = Rn[1];
+              q2 = Rn[2];
+              q3 = Rn[3];
+            }
+            // fast path of k_beta64: attempt 0's normal is the move's value if three ballots say so
+            const double z1 = z1_n;
+            double lo = -inf, hi = inf;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+              lo = vmax64(lo, z1 - bj[r] * rl[r]);      // NaN (row not in the lower set) leaves lo as it is
+              hi = vmin64(hi, z1 - bj[r] * rh[r]);
+            }
+            const double s0 = readlane_f64(r3, 0);
+            const double l0s = s0 < 0.0 ? s0 : 0.0, h0s = s0 > 0.0 ? s0 : 0.0;
+            const double l1s = s0 < -1.26 ? s0 : -1.26, h1s = s0 > 1.26 ? s0 : 1.26;
+            const double l2s = s0 < -2.51 ? s0 : -2.51, h2s = s0 > 2.51 ? s0 : 2.51;
+            double z2 = s0;
+            if (!(__ballot(lo > l1s || hi < h1s) == 0ull || __ballot(lo > l0s || hi < h2s) == 0ull ||
+                  __ballot(lo > l2s || hi < h0s) == 0ull)) {
+              wave_maxmin(lo, hi);
+              z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+            }
+            const double dz = z2 - z1;
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) bj[r] += l1[r] * dz;    // L(j, c) = 0 for j < c: rows above c do not move
+            if (lane == 0) sz[c] = z2;
+            if (i + 1 < P) z1_n = sz[__builtin_amdgcn_readfirstlane(c_n)];   // after the stores above in program order
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (serial) {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int j = lane + 64 * r;
+      if (j < P) a.beta_out[j] = bj[r];
+    }
+  }
+}
+
+// OR of v over the 64 lanes, returned wave-uniform (same DPP ladder as wave_maxmin)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+  int x = (int)v;
+  x |= __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+  x |= __builtin_amdgcn_mov_dpp(x, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+  x |= __builtin_amdgcn_mov_dpp(x, 0x141, 0xf, 0xf, true);     // row_half_mirror
+  x |= __builtin_amdgcn_mov_dpp(x, 0x140, 0xf, 0xf, true);     // row_mirror
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast15 -> rows 1, 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+// ---- the same sweeps with the ROWS split over the wavefronts: wave w owns rows 64 w + lane (one row per lane, beta_j in
+// a register).  A scan is NQ = ceil(P / 64) segments of 64 moves; at the start of a segment a lane loads its row's
+// entry of the 64 columns of L the segment will visit (one L2 latency per segment, 128 registers), and the moves
+// are taken in speculative blocks of 16 (k_beta64's scheme): assuming every move of the block takes its first
+// Box-Muller normal s (z' = s, dz = s - z_c: known up front, because a scan visits every coordinate once), each
+// wavefront walks the block on its own rows and the wavefronts meet once per block (three 16-bit masks through LDS,
+// one barrier).
+//
+// The sufficient tests of k_beta64 -- lo <= min(s, -a), hi >= max(s, b) for (a, b) in {(1.26, 1.26), (0, 2.51),
+// (2.51, 0)} -- are run here without the bounds: "lo <= p <= hi" says that z' = p keeps every constrained row
+// non-negative, beta_j + L_jc (p - z_c) >= 0 (Logit.hpp:383-391 are exactly these inequalities solved for z'), so a
+// test passes iff the rows are feasible at s, at -a and at b: six FMAs per row and move (s and the five points
+// -2.51, -1.26, 0, 1.26, 2.51), sign bits OR-ed, one ballot per test; no reciprocals, no NaN masks, one load per
+// row and move instead of three.  A block with no failing move commits.  Otherwise the moves before the first
+// failing one commit, beta_j is rolled back to that point, that one move is redone with its exact bounds
+// (split_exact: reciprocal columns, DPP max/min per wavefront, four results through LDS, the tnorm record's attempts
+// evaluated redundantly by every wavefront) and the block resumes behind it.  Same decisions as the one-wavefront
+// kernel up to the rounding of the tests' left-hand sides; same arithmetic for beta_j.
+__device__ __forceinline__ void split_exact(const double* __restrict__ Lg, const double* __restrict__ Rg,
+                                            const double* __restrict__ Rh, const double* __restrict__ RkSeg, int P, int jr,
+                                            int lane, int wave, int nq, int i, int cq, double z1q, double& bj, double* sz,
+                                            double* xl, unsigned& par, int g4)
+{
+  const int c = __builtin_amdgcn_readlane(cq, i);
+  const size_t off = (size_t)c * P + jr;
+  const double l1 = Lg[off], rl = Rg[off], rh = Rh[off];
+  const double z1 = readlane_f64(z1q, i);
+  const double* Rn = RkSeg + (size_t)i * kRec + g4;
+  const double r0 = Rn[0], r1 = Rn[1], r2 = Rn[2], r3 = Rn[3];
+  double lo = z1 - bj * rl, hi = z1 - bj * rh;       // NaN: this row does not bound the move on that side
+  wave_maxmin(lo, hi);
+  double* sl = xl + par * 8;
+  if (lane == 0) {
+    sl[wave * 2] = lo;
+    sl[wave * 2 + 1] = hi;
+  }
+  __syncthreads();
+  double glo = -__builtin_huge_val(), ghi = __builtin_huge_val();
+  for (int w = 0; w < nq; ++w) {
+    glo = vmax64(glo, sl[w * 2]);            // v_max_f64 / v_min_f64 return the other operand for a NaN
+    ghi = vmin64(ghi, sl[w * 2 + 1]);
+  }
+  par ^= 1u;
+  const double z2 = tnorm_lanes(r0, r1, r2, r3, lane, glo, ghi);
+  bj += l1 * (z2 - z1);
+  if (wave == 0 && lane == 0) sz[c] = z2;
+}
+
+// Moves [max(ustart, 16 B), min(uend, 16 B + 16)) of the segment, speculatively.  Returns the index of the first move
+// not done: uend's clamp if the block passed, else (negated) one past the move that was redone exactly.
+template <int B>
+__device__ __forceinline__ int split_block(const double (&l1seg)[64], const double* __restrict__ Lg,
+                                           const double* __restrict__ Rg, const double* __restrict__ Rh,
+                                           const double* __restrict__ RkSeg, int P, int jr, bool lastrow, int lane,
+                                           int wave, int nq, int ustart, int uend, int cq, double sq, double z1q,
+                                           double dzq, double& bj, double* sz, uint32_t* xm, double* xl, unsigned& par,
+                                           int g4)
+{
+  // straight-line over the block's 16 moves (the compiler interleaves the moves' independent test arithmetic; only
+  // beta_j's running value chains them).  Moves outside [ustart, uend) get dz = 0 and their test bits are masked off.
+  // A lane keeps its rows' verdicts as bits (no ballot per move: 48 ballots a block and their scalar bookkeeping cost
+  // more than the tests); the lanes' bits meet in one DPP OR-reduction per block.
+  const double dzm = (lane >= ustart && lane < uend) ? dzq : 0.0;
+  double bs = bj;
+  uint32_t pA = 0, pB = 0, pC = 0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    constexpr int base = 16 * B;
+    const int m = base + u;
+    const double z1 = readlane_f64(z1q, m), dz = readlane_f64(dzm, m);
+    const double l1 = l1seg[m];
+    const double lt = lastrow ? 0.0 : l1;                            // row P-1 is not constrained (Logit.hpp:383: j < P-1)
+    const double be = lt != 0.0 ? bs : 1.0;                          // L(j, c) = 0 (j < c): the row does not move
+    const double g = fma(-lt, z1, be);                               // beta_j + L (p - z_c) at p = 0
+    const double es = fma(lt, dz, be);                               //                      at p = s
+    const double e1 = fma(lt, -2.51, g), e2 = fma(lt, -1.26, g), e3 = fma(lt, 1.26, g), e4 = fma(lt, 2.51, g);
+    const uint32_t hs = (uint32_t)__double2hiint(es), h0 = (uint32_t)__double2hiint(g);
+    pA |= ((hs | (uint32_t)__double2hiint(e2) | (uint32_t)__double2hiint(e3)) >> 31) << u;   // (1.26, 1.26)
+    pB |= ((hs | h0 | (uint32_t)__double2hiint(e4)) >> 31) << u;                             // (0, 2.51)
+    pC |= ((hs | (uint32_t)__double2hiint(e1) | h0) >> 31) << u;                             // (2.51, 0)
+    bs = fma(l1, dz, bs);
+  }
+  uint32_t mA, mB, mC;
+  {
+    const int lo_u = ustart > 16 * B ? ustart - 16 * B : 0, hi_u = uend < 16 * B + 16 ? uend - 16 * B : 16;
+    const uint32_t valid = (hi_u >= 16 ? 0xFFFFu : ((1u << hi_u) - 1u)) & ~((1u << lo_u) - 1u);
+    uint32_t ab = pA | (pB << 16), cc = pC;
+    ab = wave_or_u32(ab);
+    cc = wave_or_u32(cc);
+    mA = ab & valid;
+    mB = (ab >> 16) & valid;
+    mC = cc & valid;
+  }
+  uint32_t* slot = xm + par * 16;
+  if (lane == 0) {
+    slot[wave * 4 + 0] = mA;
+    slot[wave * 4 + 1] = mB;
+    slot[wave * 4 + 2] = mC;
+  }
+  __syncthreads();
+  uint32_t A = 0, Bm = 0, C = 0;
+  for (int w = 0; w < nq; ++w) {
+    A |= slot[w * 4 + 0];
+    Bm |= slot[w * 4 + 1];
+    C |= slot[w * 4 + 2];
+  }
+  par ^= 1u;
+  const uint32_t fail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(A & Bm & C));
+  const int lo_m = ustart > 16 * B ? ustart : 16 * B, hi_m = uend < 16 * B + 16 ? uend : 16 * B + 16;
+  if (fail == 0u) {
+    bj = bs;
+    if (wave == 0 && lane >= lo_m && lane < hi_m) sz[cq] = sq;
+    return hi_m;
+  }
+  const int f = __builtin_ctz(fail);
+  const int mf = 16 * B + f;
+  // the moves before mf stand; beta_j as it was just before move mf
+  double bb = bj;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int m = 16 * B + u;
+    if (m >= ustart && u < f) bb = fma(l1seg[m], readlane_f64(dzq, m), bb);
+  }
+  if (wave == 0 && lane >= lo_m && lane < mf) sz[cq] = sq;
+  bj = bb;
+  split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, nq, mf, cq, z1q, bj, sz, xl, par, g4);
+  return -(mf + 1);
+}
+
+template <int NQ>
+__global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
+{
+  extern __shared__ double lds[];
+  if (*a.status & ST_NOT_PD) return;       // see k_beta
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
+  const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
+  const double* zz = a.work + 2 * (size_t)P * P + P;               // z
+  const double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  const int* swp = reinterpret_cast<const int*>(rec + (size_t)P * P * kRec);
+  const double* __restrict__ Rh = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;   // 1/L where L < 0, else NaN
+  double* sz = lds;                                              // z (P)
+  uint32_t* xm = reinterpret_cast<uint32_t*>(sz + P);            // [2][4 waves][4]: the blocks' test masks
+  double* xl = sz + P + 16;                                      // [2][4 waves][2]: a move's bound candidates
+  unsigned char* ptab = reinterpret_cast<unsigned char*>(xl + 16);   // ptab[k][i]: coordinate of move i of scan k
+  for (int j = t; j < P; j += nthr) sz[j] = zz[j];
+  __syncthreads();
+  // scan permutations: each scan's swaps on the identity (thread k), then composed in scan order
+  if (t < P) {
+    unsigned char* sg = ptab + t * P;
+    for (int i = 0; i < P; ++i) sg[i] = (unsigned char)i;
+    for (int i = 0; i < P - 1; ++i) {
+      const int j = swp[t * (P - 1) + i];
+      const unsigned char tmp = sg[i];
+      sg[i] = sg[j];
+      sg[j] = tmp;
+    }
+  }
+  __syncthreads();
+  for (int k = 1; k < P; ++k) {
+    int v = 0;
+    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
+    __syncthreads();
+    if (t < P) ptab[k * P + t] = (unsigned char)v;
+    __syncthreads();
+  }
+
+  const int lane = t & 63, wave = t >> 6;
+  const int j = 64 * wave + lane;
+  const int jr = j < P ? j : P - 1;          // a lane past the matrix rides on row P-1, which no test looks at
+  const bool lastrow = jr == P - 1;
+  double bj = j < P ? a.beta_prev[j] : 0.0;
+  const int g4 = (lane < 5 ? lane : 0) * 4;
+  unsigned par = 0;
+  bool spec_on = true;
+  for (int k = 0; k < P; ++k) {
+    const unsigned char* pk = ptab + k * P;
+    int nslow = 0, nblocks = 0;
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+      const int m0 = 64 * q;
+      const int mcnt = (P - m0) < 64 ? (P - m0) : 64;
+      if (mcnt <= 0) break;
+      const double* RkSeg = rec + ((size_t)k * P + m0) * kRec;
+      const bool has = lane < mcnt;
+      const int cq = has ? (int)pk[m0 + lane] : 0;                      // lane i: coordinate of move m0 + i
+      const double sq = has ? RkSeg[(size_t)lane * kRec + 3] : 0.0;     //         its first Box-Muller normal
+      const double z1q = has ? sz[cq] : 0.0;                            //         z_c before the move (a scan visits c once)
+      const double dzq = sq - z1q;
+      if (!spec_on) {                                                    // a chain pressed against its bounds: every move exactly
+        for (int i = 0; i < mcnt; ++i)
+          split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, NQ, i, cq, z1q, bj, sz, xl, par, g4);
+        nslow += mcnt;
+        continue;
+      }
+      double l1seg[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) l1seg[u] = Lg[(size_t)__builtin_amdgcn_readlane(cq, u) * P + jr];
+      int i0 = 0;
+      while (i0 < mcnt) {
+        int r;
+        if (i0 < 16)
+          r = split_block<0>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+        else if (i0 < 32)
+          r = split_block<1>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+        else if (i0 < 48)
+          r = split_block<2>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+        else
+          r = split_block<3>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+        if (r < 0) {
+          ++nslow;
+          r = -r;
+        }
+        ++nblocks;
+        i0 = r;
+      }
+    }
+    // a chain pressed against its bounds fails most blocks: stop speculating, look again every 8th scan
+    spec_on = 3 * nslow < P || ((k + 1) & 7) == 0;
+    if (a.dbg && t == 0) {
+      a.dbg[8] += (unsigned long long)nslow;
+      a.dbg[12] += (unsigned long long)nblocks;
+    }
+    __syncthreads();         // the scan's z are in LDS before the next scan gathers them
+  }
+  if (j < P) a.beta_out[j] = bj;
+}
+#undef L_
+
+}  // namespace
+
+namespace blk {
+
+size_t beta_work_doubles(int P)
+{
+  size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
+  if (P > 64 && P <= 256)    // constrained_sweeps_wide: tnorm records + swap targets after the dense stage's matrices
+    generic += (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P;   // + the second reciprocal matrix
+  const size_t small = (size_t)P * P * kRec + 2 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
+  return generic > small ? generic : small;
+}
+
+// BL_BETA_SPLIT=0: the one-wavefront sweeps (k_beta_sweeps) instead of the row-split ones, for comparison
+static bool beta_split_off()
+{
+  static const bool off = [] { const char* e = getenv("BL_BETA_SPLIT"); return e && e[0] == '0'; }();
+  return off;
+}
+
+void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
+{
+  if (a.P <= 64) {
+    const int ld = a.P + 1;
+    const size_t lds = (3 * (size_t)a.P * ld + 2 * (size_t)a.P) * 8 + ((size_t)a.P + 1 + (size_t)a.P * a.P + 1) * 4 +
+                       2 * (size_t)a.P * kRec * 8 + 32;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_beta64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
+    return;
+  }
+  size_t lds = 0;
+  if (mode == B_CONSTRAINED) {
+    const size_t pp = (size_t)a.P * a.P * 8;
+    if (a.P <= 256)   // constrained_sweeps_wide: two scans of records, z, byte permutation table
+      lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;
+    else
+      lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8 + (pp <= 128 * 1024 ? pp : 0);
+  }
+  const bool wide = mode == B_CONSTRAINED && a.P <= 256;   // the dense stage then runs with its static LDS only
+  if (!wide && lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), wide ? 0 : lds, s, a, mode);
+  if (wide && !beta_split_off()) {
+    const size_t l2 = ((size_t)a.P + 32) * 8 + (size_t)a.P * a.P;
+    const int nq = (a.P + 63) / 64;
+    auto fn = nq == 2 ? k_beta_sweeps_split<2> : nq == 3 ? k_beta_sweeps_split<3> : k_beta_sweeps_split<4>;
+    if (l2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), l2, s, a);
+  } else if (wide) {
+    if (a.P <= 128) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<2>, dim3(1), dim3(kBlock), lds, s, a);
+    } else {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a);
+    }
+  }
+}
+
+}  // namespace blk

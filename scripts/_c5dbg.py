@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0,'.')
+import numpy as np, torch
+from bayeslogit_amd import device as D
+sys.argv=['x']
+import bench
+dev=torch.device('cuda:0')
+N,P=int(os.environ.get('BL_N','4000000')),256
+X,y,bt=bench.synth_logit(D,dev,N,P)
+nn=torch.ones(N,dtype=torch.float64,device=dev)
+sh=D.GibbsShard(X,y,nn,seed=20240004)
+sh.set_prior(np.zeros(P),np.eye(P)*0.01); sh.set_bp_local(); sh.finish_bp(); sh.set_beta(np.zeros(P))
+for s in range(12):
+    sh.sweep_local(s,None); sh.draw_beta(s,1)
+    print("sweep",s, "min beta", float(sh.beta()[:-1].min()), flush=True)
+D.sync_status()
