@@ -179,14 +179,14 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
   static const bool dbg = getenv("BL_BETA_DEBUG") != nullptr;   // development aid: phase timing of the beta stage
   static unsigned long long* dbuf = nullptr;
   if (dbg) {
-    if (!dbuf) (void)hipMalloc((void**)&dbuf, 16 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), h->stream);
+    if (!dbuf) (void)hipMalloc((void**)&dbuf, 32 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbuf, 0, 32 * sizeof(unsigned long long), h->stream);
     a.dbg = dbuf;
   }
   blk::launch_beta(a, constrain ? blk::B_CONSTRAINED : blk::B_MVN, h->stream);
   BL_HIP_TRY(hipGetLastError());
   if (dbg) {
-    unsigned long long st[16];
+    unsigned long long st[32];
     (void)hipMemcpyAsync(st, dbuf, sizeof(st), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
     fprintf(stderr, "beta stage (us): chol %.1f inverse %.1f rest of dense (wave 0; waves 1-3 generate randoms) %.1f scan tables %.1f serial %.1f\n",
@@ -195,6 +195,9 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
     if (st[7]) fprintf(stderr, "  moves redone move by move: %llu; shader clock over the sweeps: %.0f MHz\n", st[8],
                        (double)(st[10] - st[9]) / ((st[6] - st[7]) / 100.0));
     if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups\n", st[8], st[12]);
+    if (st[19]) fprintf(stderr, "  shader cycles: sweeps %llu = segment set-up %llu + blocks that passed %llu + blocks with an exact move %llu + rest\n",
+                        st[19], st[16], st[17], st[18]);
+    if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu\n", st[20], st[21], st[22]);
     if (st[11]) fprintf(stderr, "  random inputs generated (waves 1-3) after %.1f us\n", (st[11] - st[0]) / 100.0);
     if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }

@@ -1404,13 +1404,70 @@ __device__ __forceinline__ int split_block(const double (&l1seg)[64], const doub
                                            const double* __restrict__ RkSeg, int P, int jr, bool lastrow, int lane,
                                            int wave, int nq, int ustart, int uend, int cq, double sq, double z1q,
                                            double dzq, double& bj, double* sz, uint32_t* xm, double* xl, unsigned& par,
-                                           int g4)
+                                           int g4, double* zdw, uint32_t* x1, long long (&tim)[4], bool prof)
 {
   // straight-line over the block's 16 moves (the compiler interleaves the moves' independent test arithmetic; only
   // beta_j's running value chains them).  Moves outside [ustart, uend) get dz = 0 and their test bits are masked off.
   // A lane keeps its rows' verdicts as bits (no ballot per move: 48 ballots a block and their scalar bookkeeping cost
   // more than the tests); the lanes' bits meet in one DPP OR-reduction per block.
   const double dzm = (lane >= ustart && lane < uend) ? dzq : 0.0;
+  const int lo_m = ustart > 16 * B ? ustart : 16 * B, hi_m = uend < 16 * B + 16 ? uend : 16 * B + 16;
+  const uint32_t valid = ((hi_m - 16 * B) >= 16 ? 0xFFFFu : ((1u << (hi_m - 16 * B)) - 1u)) & ~((1u << (lo_m - 16 * B)) - 1u);
+  // First the cheap test: the whole of [-2.51, 2.51] and s feasible for every row (beta_j - L z_c - 2.51 |L| >= 0 covers
+  // both ends at once; beta_j after the move is the value the chain needs anyway), which implies test (1.26, 1.26).
+  // Three FMAs and an OR per row and move, one verdict for the block (a block that fails goes to the tests below, which
+  // locate the move); z_c and dz come back from LDS as wave-uniform vector operands (broadcast reads, all in flight
+  // together) instead of four v_readlane per move.  ~99 % of the moves of a settled chain pass.
+  {
+    const long long q0 = prof ? clock64() : 0;
+    if ((lane >> 4) == B) {
+      zdw[2 * (lane & 15)] = (lane >= ustart && lane < uend) ? z1q : 0.0;
+      zdw[2 * (lane & 15) + 1] = dzm;
+    }
+    double z1v[16], dzv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      z1v[u] = zdw[2 * u];
+      dzv[u] = zdw[2 * u + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);       // all sixteen reads in flight before the first use
+    if (prof) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tim[0] += clock64() - q0;
+    }
+    const long long q1 = prof ? clock64() : 0;
+    double bsv[17], gv[16];
+    bsv[0] = bj;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double l1 = l1seg[16 * B + u];
+      bsv[u + 1] = fma(l1, dzv[u], bsv[u]);
+      gv[u] = fma(-l1, z1v[u], bsv[u]);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double wu = ((valid >> u) & 1u) ? 2.51 : 0.0;            // wave-uniform: a move outside the range tests nothing
+      const double e = fma(-wu, fabs(l1seg[16 * B + u]), gv[u]);
+      acc |= (uint32_t)__double2hiint(e) | (uint32_t)__double2hiint(bsv[u + 1]);
+    }
+    const bool bad1 = !lastrow && (acc >> 31) != 0u;
+    const uint32_t any1 = __ballot(bad1) != 0ull ? 1u : 0u;
+    if (prof) tim[1] += clock64() - q1;
+    const long long q2 = prof ? clock64() : 0;
+    uint32_t* slot1 = x1 + par * 4;
+    if (lane == 0) slot1[wave] = any1;
+    __syncthreads();
+    const uint4 sv = *reinterpret_cast<const uint4*>(slot1);
+    par ^= 1u;
+    const int anyf = __builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w));
+    if (prof) tim[2] += clock64() - q2;
+    if (anyf == 0) {
+      bj = bsv[16];
+      if (wave == 0 && lane >= lo_m && lane < hi_m) sz[cq] = sq;
+      return hi_m;
+    }
+  }
   double bs = bj;
   uint32_t pA = 0, pB = 0, pC = 0;
 #pragma unroll
@@ -1419,21 +1476,20 @@ __device__ __forceinline__ int split_block(const double (&l1seg)[64], const doub
     const int m = base + u;
     const double z1 = readlane_f64(z1q, m), dz = readlane_f64(dzm, m);
     const double l1 = l1seg[m];
-    const double lt = lastrow ? 0.0 : l1;                            // row P-1 is not constrained (Logit.hpp:383: j < P-1)
-    const double be = lt != 0.0 ? bs : 1.0;                          // L(j, c) = 0 (j < c): the row does not move
-    const double g = fma(-lt, z1, be);                               // beta_j + L (p - z_c) at p = 0
-    const double es = fma(lt, dz, be);                               //                      at p = s
-    const double e1 = fma(lt, -2.51, g), e2 = fma(lt, -1.26, g), e3 = fma(lt, 1.26, g), e4 = fma(lt, 2.51, g);
+    // a row with L(j, c) = 0 (j < c) does not move: its three values are beta_j itself, non-negative in a feasible chain
+    // (a negative one only sends the move to the exact path, which ignores such rows as Logit.hpp:384-391 does)
+    const double g = fma(-l1, z1, bs);                               // beta_j + L (p - z_c) at p = 0
+    const double es = fma(l1, dz, bs);                               //                      at p = s: beta_j after the move
+    const double e1 = fma(l1, -2.51, g), e2 = fma(l1, -1.26, g), e3 = fma(l1, 1.26, g), e4 = fma(l1, 2.51, g);
     const uint32_t hs = (uint32_t)__double2hiint(es), h0 = (uint32_t)__double2hiint(g);
     pA |= ((hs | (uint32_t)__double2hiint(e2) | (uint32_t)__double2hiint(e3)) >> 31) << u;   // (1.26, 1.26)
     pB |= ((hs | h0 | (uint32_t)__double2hiint(e4)) >> 31) << u;                             // (0, 2.51)
     pC |= ((hs | (uint32_t)__double2hiint(e1) | h0) >> 31) << u;                             // (2.51, 0)
-    bs = fma(l1, dz, bs);
+    bs = es;
   }
+  if (lastrow) pA = pB = pC = 0u;                                    // row P-1 is not constrained (Logit.hpp:383: j < P-1)
   uint32_t mA, mB, mC;
   {
-    const int lo_u = ustart > 16 * B ? ustart - 16 * B : 0, hi_u = uend < 16 * B + 16 ? uend - 16 * B : 16;
-    const uint32_t valid = (hi_u >= 16 ? 0xFFFFu : ((1u << hi_u) - 1u)) & ~((1u << lo_u) - 1u);
     uint32_t ab = pA | (pB << 16), cc = pC;
     ab = wave_or_u32(ab);
     cc = wave_or_u32(cc);
@@ -1456,7 +1512,6 @@ __device__ __forceinline__ int split_block(const double (&l1seg)[64], const doub
   }
   par ^= 1u;
   const uint32_t fail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(A & Bm & C));
-  const int lo_m = ustart > 16 * B ? ustart : 16 * B, hi_m = uend < 16 * B + 16 ? uend : 16 * B + 16;
   if (fail == 0u) {
     bj = bs;
     if (wave == 0 && lane >= lo_m && lane < hi_m) sz[cq] = sq;
@@ -1492,8 +1547,11 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
   double* sz = lds;                                              // z (P)
   uint32_t* xm = reinterpret_cast<uint32_t*>(sz + P);            // [2][4 waves][4]: the blocks' test masks
   double* xl = sz + P + 16;                                      // [2][4 waves][2]: a move's bound candidates
-  unsigned char* ptab = reinterpret_cast<unsigned char*>(xl + 16);   // ptab[k][i]: coordinate of move i of scan k
+  double* zdw = xl + 16 + 32 * (t >> 6);                         // [4 waves][16][2]: a block's (z_c, dz), read back wave-uniform
+  uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16 + 128);     // [2][4 waves]: the blocks' cheap-test verdicts (slots of unused waves stay 0)
+  unsigned char* ptab = reinterpret_cast<unsigned char*>(xl + 16 + 128 + 4);   // ptab[k][i]: coordinate of move i of scan k
   for (int j = t; j < P; j += nthr) sz[j] = zz[j];
+  if (t < 8) x1[t] = 0u;
   __syncthreads();
   // scan permutations: each scan's swaps on the identity (thread k), then composed in scan order
   if (t < P) {
@@ -1523,6 +1581,22 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
   const int g4 = (lane < 5 ? lane : 0) * 4;
   unsigned par = 0;
   bool spec_on = true;
+  // a lane's entries of the 64 columns of L a segment visits, fetched one segment ahead (the tables of every scan exist)
+#define BL_FETCH_SEG(dst, kk, qq)                                                                        \
+  {                                                                                                      \
+    const int m0n = 64 * (qq);                                                                           \
+    const bool hasn = lane < P - m0n;                                                                    \
+    cq_n = hasn ? (int)ptab[(kk) * P + m0n + lane] : 0;                                                  \
+    sq_n = hasn ? rec[((size_t)(kk) * P + m0n + lane) * kRec + 3] : 0.0;                                 \
+    _Pragma("unroll") for (int u = 0; u < 64; ++u) dst[u] = Lg[(size_t)__builtin_amdgcn_readlane(cq_n, u) * P + jr]; \
+  }
+  double l1nxt[64];
+  int cq_n;             // lane i: coordinate of move i of the next segment
+  double sq_n;          //         its first Box-Muller normal
+  BL_FETCH_SEG(l1nxt, 0, 0)
+  const bool prof = a.dbg != nullptr;
+  long long cSeg = 0, cOk = 0, cFail = 0, cPre = prof ? clock64() : 0;
+  long long tim[4] = {0, 0, 0, 0};
   for (int k = 0; k < P; ++k) {
     const unsigned char* pk = ptab + k * P;
     int nslow = 0, nblocks = 0;
@@ -1533,30 +1607,45 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
       if (mcnt <= 0) break;
       const double* RkSeg = rec + ((size_t)k * P + m0) * kRec;
       const bool has = lane < mcnt;
-      const int cq = has ? (int)pk[m0 + lane] : 0;                      // lane i: coordinate of move m0 + i
-      const double sq = has ? RkSeg[(size_t)lane * kRec + 3] : 0.0;     //         its first Box-Muller normal
+      const long long ts0 = prof ? clock64() : 0;
+      const int cq = cq_n;                                              // lane i: coordinate of move m0 + i
+      const double sq = sq_n;                                           //         its first Box-Muller normal
       const double z1q = has ? sz[cq] : 0.0;                            //         z_c before the move (a scan visits c once)
       const double dzq = sq - z1q;
+      double l1seg[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) l1seg[u] = l1nxt[u];
+      {
+        int qn = q + 1, kn = k;
+        if (64 * qn >= P) {
+          qn = 0;
+          kn = k + 1;
+        }
+        if (kn < P) BL_FETCH_SEG(l1nxt, kn, qn)
+      }
       if (!spec_on) {                                                    // a chain pressed against its bounds: every move exactly
         for (int i = 0; i < mcnt; ++i)
           split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, NQ, i, cq, z1q, bj, sz, xl, par, g4);
         nslow += mcnt;
         continue;
       }
-      double l1seg[64];
-#pragma unroll
-      for (int u = 0; u < 64; ++u) l1seg[u] = Lg[(size_t)__builtin_amdgcn_readlane(cq, u) * P + jr];
       int i0 = 0;
+      if (prof) cSeg += clock64() - ts0;
       while (i0 < mcnt) {
         int r;
+        const long long tb0 = prof ? clock64() : 0;
         if (i0 < 16)
-          r = split_block<0>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+          r = split_block<0>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
         else if (i0 < 32)
-          r = split_block<1>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+          r = split_block<1>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
         else if (i0 < 48)
-          r = split_block<2>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+          r = split_block<2>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
         else
-          r = split_block<3>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4);
+          r = split_block<3>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
+        if (prof) {
+          if (r < 0) cFail += clock64() - tb0;
+          else cOk += clock64() - tb0;
+        }
         if (r < 0) {
           ++nslow;
           r = -r;
@@ -1574,6 +1663,16 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
     __syncthreads();         // the scan's z are in LDS before the next scan gathers them
   }
   if (j < P) a.beta_out[j] = bj;
+  if (prof && t == 0) {
+    a.dbg[16] = (unsigned long long)cSeg;
+    a.dbg[17] = (unsigned long long)cOk;
+    a.dbg[18] = (unsigned long long)cFail;
+    a.dbg[19] = (unsigned long long)(clock64() - cPre);
+    a.dbg[20] = (unsigned long long)tim[0];
+    a.dbg[21] = (unsigned long long)tim[1];
+    a.dbg[22] = (unsigned long long)tim[2];
+  }
+#undef BL_FETCH_SEG
 }
 #undef L_
 
@@ -1621,7 +1720,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
     (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), wide ? 0 : lds, s, a, mode);
   if (wide && !beta_split_off()) {
-    const size_t l2 = ((size_t)a.P + 32) * 8 + (size_t)a.P * a.P;
+    const size_t l2 = ((size_t)a.P + 32 + 128 + 4) * 8 + (size_t)a.P * a.P;
     const int nq = (a.P + 63) / 64;
     auto fn = nq == 2 ? k_beta_sweeps_split<2> : nq == 3 ? k_beta_sweeps_split<3> : k_beta_sweeps_split<4>;
     if (l2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);

@@ -1,5 +1,7 @@
+"""A few sweeps of the C5-shaped constrained chain (P = 256) for `rocprofv3 --kernel-trace --stats`: the per-kernel
+split between the X pass and the replicated beta stage.   BL_N=4000000 python scripts/gpu_c5.py"""
 import sys, os
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from bayeslogit_amd import device as D
 sys.argv=['x']
