@@ -27,140 +27,240 @@ __device__ __forceinline__ double dppmov_f64(double v)      // every lane has a 
 // ================================================================ P x P stage
 #define M_(M, i, j) ((M)[(size_t)(i) + (size_t)(j) * (size_t)P])
 
-// Whole-workgroup dense routines on column-major matrices in global memory (they live in L2), right-looking, one
-// pivot per step.  Threads are a 32 x (blockDim/32) grid: the 32 run down a column (consecutive addresses), the
-// others across columns; the pivot row / column of the step is staged in LDS so that no thread walks a row of a
-// column-major matrix.  Every element receives the same updates in the same order as the textbook loops
-// (k ascending, one product subtracted per step).
-constexpr int kMaxP = 1024;
+// ---- Blocked dense routines for P > 64: one workgroup of 512 threads (a 32 x 16 grid), matrices in global memory
+// (they live in L2), panels of 32 rows.  A panel is first brought up to date with everything before it (a tiled
+// product through LDS: no barrier per pivot, k runs inside a thread), then finished on chip: the 32 x 32 diagonal
+// block by one wavefront in registers, the rest of the panel by one thread per column against that block in LDS.
+// Every element receives the products of the textbook loops in the same order (k ascending for the factorisations
+// and the forward solve, descending for the backward solve; one product subtracted at a time, then the division), so
+// the results do not depend on the blocking.
+constexpr int kPB = 32;             // panel height = depth of a k tile
+constexpr int kCT = 128;            // columns of one update chunk
+constexpr int kDenseThreads = 512;  // 2 waves / SIMD: 256 registers per lane (the panel routines keep 32-double columns in registers)
+constexpr int kNY = kDenseThreads / 32, kCPT = kCT / kNY;   // thread grid 32 x kNY, kCPT columns of a chunk per thread
 
-// In-place A = U'U (upper triangle holds U).
-__device__ bool wg_chol_upper(double* A, int P, int* bad)
+struct DenseLds {
+  double A[kPB][kPB + 1];           // A[kk][ii]: the panel's own columns of the factor, rows of the k tile
+  double B[kPB][kCT + 1];           // B[kk][cc]: the k tile's rows of the chunk's columns
+  double D[kPB][kPB + 1];           // the diagonal block of the factor, D[i][j], i <= j (zero below, and past the matrix)
+  double Dt[kPB][kPB + 1];          // its transpose (backward solves read the block by columns)
+  int bad;
+};
+
+struct View {                       // element (r, c) at p[r sr + c sc]
+  double* p;
+  int sr, sc;
+  __device__ __forceinline__ double& at(int r, int c) const { return p[(size_t)r * (size_t)sr + (size_t)c * (size_t)sc]; }
+};
+
+__device__ __forceinline__ double rl64(double v, int l)
 {
-  __shared__ double srow[kMaxP];
-  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
-  for (int k = 0; k < P; ++k) {
-    const double akk = M_(A, k, k);
-    if (!(akk > 0.0)) {
-      if (t == 0) *bad = 1;
-      return false;
-    }
-    const double d = sqrt(akk);
-    __syncthreads();
-    if (t == 0) M_(A, k, k) = d;
-    for (int j = k + 1 + t; j < P; j += nt) {
-      const double v = M_(A, k, j) / d;
-      M_(A, k, j) = v;
-      srow[j] = v;
-    }
-    __syncthreads();
-    for (int j = k + 1 + ty; j < P; j += ny) {
-      const double sj = srow[j];
-      for (int i = k + 1 + tx; i <= j; i += 32) M_(A, i, j) -= srow[i] * sj;
-    }
-    __syncthreads();
-  }
-  return true;
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// In-place S = L L' (lower triangle holds L; strict upper zeroed).
-__device__ bool wg_chol_lower(double* S, int P, int* bad)
+// C(i0 + i, c) -= sum_k A(k, i0 + i) B(k, c) over k in [k_lo, k_hi) (REV: from k_hi - 1 down), i < pb, c in [c_lo, c_hi);
+// tri: only c >= i0 + i (the triangle of a factorisation).
+template <bool REV>
+__device__ __forceinline__ void panel_update(DenseLds& L, View A, View B, View C, int i0, int pb, int c_lo, int c_hi, int k_lo, int k_hi,
+                             bool tri)
 {
-  __shared__ double scol[kMaxP];
-  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
-  for (int k = 0; k < P; ++k) {
-    const double akk = M_(S, k, k);
-    if (!(akk > 0.0)) {
-      if (t == 0) *bad = 1;
-      return false;
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int ntile = (k_hi - k_lo + kPB - 1) / kPB;
+  for (int cc = c_lo; cc < c_hi; cc += kCT) {
+    const int cn = c_hi - cc < kCT ? c_hi - cc : kCT;
+    double acc[kCPT];
+    bool own[kCPT];
+#pragma unroll
+    for (int m = 0; m < kCPT; ++m) {
+      const int c = ty + kNY * m;
+      own[m] = tx < pb && c < cn && !(tri && cc + c < i0 + tx);
+      acc[m] = own[m] ? C.at(i0 + tx, cc + c) : 0.0;
     }
-    const double d = sqrt(akk);
-    __syncthreads();
-    if (t == 0) M_(S, k, k) = d;
-    for (int i = k + 1 + t; i < P; i += nt) {
-      const double v = M_(S, i, k) / d;
-      M_(S, i, k) = v;
-      scol[i] = v;
-    }
-    __syncthreads();
-    for (int j = k + 1 + ty; j < P; j += ny) {
-      const double sj = scol[j];
-      for (int i = j + tx; i < P; i += 32) M_(S, i, j) -= scol[i] * sj;
-    }
-    __syncthreads();
-  }
-  for (int e = t; e < P * P; e += nt) {
-    const int i = e % P, j = e / P;
-    if (i < j) M_(S, i, j) = 0.0;
-  }
-  __syncthreads();
-  return true;
-}
-
-// B (P x nrhs, leading dim ldb) <- U'^{-1} B : forward substitution, all columns at once.  tri: B is lower
-// triangular on entry (the identity, when inverting) and stays so: column c is zero above row c and is skipped there.
-__device__ void wg_solve_Ut(const double* U, double* B, int P, int nrhs, int ldb, bool tri = false)
-{
-  __shared__ double su[kMaxP], sb[kMaxP];
-  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
-  for (int i = 0; i < P; ++i) {
-    const double d = M_(U, i, i);
-    const int cend = tri ? (i + 1 < nrhs ? i + 1 : nrhs) : nrhs;      // columns whose row i can be non-zero
-    for (int c = t; c < cend; c += nt) {
-      const double v = B[i + (size_t)c * ldb] / d;
-      B[i + (size_t)c * ldb] = v;
-      sb[c] = v;
-    }
-    for (int j = i + 1 + t; j < P; j += nt) su[j] = M_(U, i, j);
-    __syncthreads();
-    if (nrhs == 1) {
-      const double b0 = sb[0];
-      for (int j = i + 1 + t; j < P; j += nt) B[j] -= su[j] * b0;
-    } else {
-      for (int c = ty; c < cend; c += ny) {
-        const double bc = sb[c];
-        double* col = B + (size_t)c * ldb;
-        for (int j = i + 1 + tx; j < P; j += 32) col[j] -= su[j] * bc;
+    // a tile's operands are fetched into registers while the tile before it is being used (an L2 round trip is ~2 us)
+    constexpr int kQA = kPB * kPB / kDenseThreads, kQB = kPB * kCT / kDenseThreads;
+    double ra[kQA], rb[kQB];
+    auto tile_of = [&](int ti, int& k0, int& kt) {
+      if (!REV) {
+        k0 = k_lo + kPB * ti;
+        kt = k_hi - k0 < kPB ? k_hi - k0 : kPB;
+      } else {
+        const int hi = k_hi - kPB * ti;
+        k0 = hi - kPB > k_lo ? hi - kPB : k_lo;
+        kt = hi - k0;
+      }
+    };
+    auto fetch = [&](int ti) {
+      int k0, kt;
+      tile_of(ti, k0, kt);
+#pragma unroll
+      for (int q = 0; q < kQA; ++q) {
+        const int e = t + kDenseThreads * q;
+        const int kk = A.sr <= A.sc ? e & 31 : e >> 5, ii = A.sr <= A.sc ? e >> 5 : e & 31;
+        ra[q] = (kk < kt && ii < pb) ? A.at(k0 + kk, i0 + ii) : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        const int e = t + kDenseThreads * q;
+        const int kk = B.sr <= B.sc ? e & 31 : e / kCT, c = B.sr <= B.sc ? e >> 5 : e & (kCT - 1);
+        rb[q] = (kk < kt && c < cn) ? B.at(k0 + kk, cc + c) : 0.0;
+      }
+    };
+    if (ntile > 0) fetch(0);
+    for (int ti = 0; ti < ntile; ++ti) {
+      int k0, kt;
+      tile_of(ti, k0, kt);
+      __syncthreads();                       // the tile before this one has been used
+#pragma unroll
+      for (int q = 0; q < kQA; ++q) {
+        const int e = t + kDenseThreads * q;
+        const int kk = A.sr <= A.sc ? e & 31 : e >> 5, ii = A.sr <= A.sc ? e >> 5 : e & 31;
+        L.A[kk][ii] = ra[q];
+      }
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        const int e = t + kDenseThreads * q;
+        const int kk = B.sr <= B.sc ? e & 31 : e / kCT, c = B.sr <= B.sc ? e >> 5 : e & (kCT - 1);
+        L.B[kk][c] = rb[q];
+      }
+      __syncthreads();
+      if (ti + 1 < ntile) fetch(ti + 1);
+      if (!REV) {
+        for (int kk = 0; kk < kt; ++kk) {
+          const double av = L.A[kk][tx];
+#pragma unroll
+          for (int m = 0; m < kCPT; ++m) acc[m] -= av * L.B[kk][ty + kNY * m];
+        }
+      } else {
+        for (int kk = kt - 1; kk >= 0; --kk) {
+          const double av = L.A[kk][tx];
+#pragma unroll
+          for (int m = 0; m < kCPT; ++m) acc[m] -= av * L.B[kk][ty + kNY * m];
+        }
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kCPT; ++m)
+      if (own[m]) C.at(i0 + tx, cc + ty + kNY * m) = acc[m];
   }
 }
-// B <- U^{-1} B : backward substitution
-__device__ void wg_solve_U(const double* U, double* B, int P, int nrhs, int ldb)
+
+// The pb x pb diagonal block of a factorisation on one wavefront: lane j keeps column j (rows i <= j) in registers, the
+// pivot row goes round by v_readlane.  u_kk = sqrt(a_kk), u_kj = a_kj / u_kk, a_ij -= u_ki u_kj: the reference's LAPACK
+// order.  Leaves the block in T and in L.D; a non-positive pivot sets L.bad.
+__device__ __forceinline__ void diag_chol(DenseLds& L, View T, int i0, int pb, int lane)
 {
-  __shared__ double su[kMaxP], sb[kMaxP];
-  const int t = threadIdx.x, nt = (int)blockDim.x, tx = t & 31, ty = t >> 5, ny = nt >> 5;
-  for (int i = P - 1; i >= 0; --i) {
-    const double d = M_(U, i, i);
-    for (int c = t; c < nrhs; c += nt) {
-      const double v = B[i + (size_t)c * ldb] / d;
-      B[i + (size_t)c * ldb] = v;
-      sb[c] = v;
-    }
-    for (int j = t; j < i; j += nt) su[j] = M_(U, j, i);
-    __syncthreads();
-    if (nrhs == 1) {
-      const double b0 = sb[0];
-      for (int j = t; j < i; j += nt) B[j] -= su[j] * b0;
-    } else {
-      for (int c = ty; c < nrhs; c += ny) {
-        const double bc = sb[c];
-        double* col = B + (size_t)c * ldb;
-        for (int j = tx; j < i; j += 32) col[j] -= su[j] * bc;
+  double col[kPB];
+  const bool act = lane < pb;
+#pragma unroll
+  for (int i = 0; i < kPB; ++i) col[i] = (act && i <= lane) ? T.at(i0 + i, i0 + lane) : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < kPB; ++k) {
+    if (k < pb && ok) {
+      const double akk = rl64(col[k], k);
+      if (!(akk > 0.0)) {
+        ok = false;
+      } else {
+        const double d = sqrt(akk);
+        col[k] = lane == k ? d : col[k] / d;
+#pragma unroll
+        for (int i = k + 1; i < kPB; ++i) {
+          const double uki = rl64(col[k], i);
+          col[i] -= uki * col[k];
+        }
       }
     }
-    __syncthreads();
+  }
+  if (!ok && lane == 0) L.bad = 1;
+#pragma unroll
+  for (int i = 0; i < kPB; ++i)
+    if (act && i <= lane) {
+      T.at(i0 + i, i0 + lane) = col[i];
+      L.D[i][lane] = col[i];
+    }
+}
+
+// Rows i0 .. i0 + pb - 1 of the columns [c_lo, c_hi) of B against the diagonal block, one thread per column (32 values
+// in registers): forward (U' y = b: for i ascending, y_i = b_i / u_ii, then b_j -= u_ij y_i for j > i, from L.D's row i)
+// or REV (U x = b: i descending, b_j -= u_ji x_i for j < i, from L.Dt's row i).  Column-oriented so that the updates of a
+// step are independent; each element still receives its products in the order of the dot-product form.
+template <bool REV>
+__device__ __forceinline__ void panel_solve(const DenseLds& L, View B, int i0, int pb, int c_lo, int c_hi)
+{
+  for (int c = c_lo + (int)threadIdx.x; c < c_hi; c += kDenseThreads) {
+    double v[kPB];
+#pragma unroll
+    for (int i = 0; i < kPB; ++i) v[i] = i < pb ? B.at(i0 + i, c) : 0.0;
+    if (!REV) {
+#pragma unroll
+      for (int i = 0; i < kPB; ++i) {
+        if (i < pb) {
+          v[i] = v[i] / L.D[i][i];
+#pragma unroll
+          for (int j = i + 1; j < kPB; ++j) v[j] -= L.D[i][j] * v[i];     // rows >= pb: zeros, never stored
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads of later steps where they are: 32 steps of them do not fit the registers
+      }
+    } else {
+#pragma unroll
+      for (int i = kPB - 1; i >= 0; --i) {
+        if (i < pb) {
+          v[i] = v[i] / L.Dt[i][i];
+#pragma unroll
+          for (int j = i - 1; j >= 0; --j) v[j] -= L.Dt[i][j] * v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPB; ++i)
+      if (i < pb) B.at(i0 + i, c) = v[i];
   }
 }
-// b <- L^{-1} b : forward substitution, single rhs
-__device__ void wg_solve_L(const double* L, double* b, int P)
+
+// In-place factorisation of the symmetric matrix whose triangle element (i, j), i <= j, is T.at(i, j): T <- U, A = U'U.
+// View{A, 1, P}: the upper triangle of a column-major matrix (chol 'U'); View{S, P, 1}: its lower triangle, S = L L'
+// with L = U' (chol 'L').
+__device__ __forceinline__ bool wg_chol(DenseLds& L, View T, int P)
 {
   const int t = threadIdx.x;
-  for (int i = 0; i < P; ++i) {
-    if (t == 0) b[i] /= M_(L, i, i);
+  if (t == 0) L.bad = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < P; i0 += kPB) {
+    const int pb = P - i0 < kPB ? P - i0 : kPB;
+    if (i0 > 0) panel_update<false>(L, T, T, T, i0, pb, i0, P, 0, i0, true);
     __syncthreads();
-    for (int j = i + 1 + t; j < P; j += (int)blockDim.x) b[j] -= M_(L, j, i) * b[i];
+    if (t < 64) diag_chol(L, T, i0, pb, t);
+    __syncthreads();
+    if (L.bad) return false;
+    if (i0 + pb < P) panel_solve<false>(L, T, i0, pb, i0 + pb, P);
+    __syncthreads();
+  }
+  return true;
+}
+
+// Columns [c_lo, c_hi) of B <- U'^{-1} B (forward) or, REV, U^{-1} B (backward); U.at(i, j), i <= j, the factor.
+template <bool REV>
+__device__ __forceinline__ void wg_trsm(DenseLds& L, View U, View B, int P, int c_lo, int c_hi)
+{
+  const int np = (P + kPB - 1) / kPB, t = threadIdx.x;
+  for (int pi = 0; pi < np; ++pi) {
+    const int i0 = (REV ? np - 1 - pi : pi) * kPB;
+    const int pb = P - i0 < kPB ? P - i0 : kPB;
+    if (!REV) {
+      if (i0 > 0) panel_update<false>(L, U, B, B, i0, pb, c_lo, c_hi, 0, i0, false);
+    } else {
+      if (i0 + pb < P) panel_update<true>(L, View{U.p, U.sc, U.sr}, B, B, i0, pb, c_lo, c_hi, i0 + pb, P, false);
+    }
+    __syncthreads();
+    for (int e = t; e < kPB * kPB; e += kDenseThreads) {
+      const int i = e & 31, j = e >> 5;
+      const double u = (i <= j && j < pb) ? U.at(i0 + i, i0 + j) : 0.0;
+      if (!REV) L.D[i][j] = u;
+      else L.Dt[j][i] = u;
+    }
+    __syncthreads();
+    panel_solve<REV>(L, B, i0, pb, c_lo, c_hi);
     __syncthreads();
   }
 }
@@ -176,62 +276,92 @@ __device__ __forceinline__ double wave_min(double v)
   return v;
 }
 
-__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg);
+__device__ void constrained_wide_records(const blk::BetaArgs& a, int t, int nthr);
+__device__ void constrained_wide_reciprocals(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg);
 
-__global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
+// P > 64, stage 1 (one workgroup): PP = P0 + X'Omega X, U = chol(PP); the EM solve and the unconstrained draw end here.
+__global__ __launch_bounds__(kDenseThreads) void k_beta_factor(blk::BetaArgs a, int mode)
 {
-  extern __shared__ double lds[];          // constrained mode: L (P*P) when it fits, then beta, z (P each), perm
+  __shared__ DenseLds L;
   // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
-  // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
+  // the chain is dead, and the stages behind this one would read a workspace nobody prepared
   if (*a.status & ST_NOT_PD) return;
   const int P = a.P, t = threadIdx.x;
   double* A = a.work;                      // PP, then U
-  double* S = a.work + (size_t)P * P;      // PP^{-1}
   double* mP = a.work + 2 * (size_t)P * P; // posterior mean
   double* zz = mP + P;
-  __shared__ int bad;
-  if (t == 0) bad = 0;
-  for (int e = t; e < P * P; e += (int)blockDim.x) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
+  for (int e = t; e < P * P; e += kDenseThreads) A[e] = a.PPsum[e] + a.P0[e];   // PP = P0 + X'OmX
   __syncthreads();
-  if (!wg_chol_upper(A, P, &bad)) {
-    __syncthreads();
+  const View U{A, 1, P};
+  if (!wg_chol(L, U, P)) {
     if (t == 0) atomicOr(a.status, ST_NOT_PD);
     return;
   }
+  if (mode != blk::B_SOLVE && mode != blk::B_MVN) return;
 
-  if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
-    for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
-    if (mode == blk::B_MVN && t < P) {
-      // eps_i = r.norm(0,1), i = 0..P-1 in stream order: normal i is exactly block i
-      Stream r;
-      r.init(a.seed, 0, DOM_BETA, a.epoch);
-      for (int i = t; i < P; i += (int)blockDim.x) {
-        r.blk = (uint32_t)i;
-        r.has = false;
-        zz[i] = r.norm(0.0, 1.0);
-      }
+  for (int j = t; j < P; j += kDenseThreads) mP[j] = a.bP[j];
+  if (mode == blk::B_MVN && t < P) {
+    // eps_i = r.norm(0,1), i = 0..P-1 in stream order: normal i is exactly block i
+    Stream r;
+    r.init(a.seed, 0, DOM_BETA, a.epoch);
+    for (int i = t; i < P; i += kDenseThreads) {
+      r.blk = (uint32_t)i;
+      r.has = false;
+      zz[i] = r.norm(0.0, 1.0);
     }
-    __syncthreads();
-    wg_solve_Ut(A, mP, P, 1, P);
-    wg_solve_U(A, mP, P, 1, P);
-    if (mode == blk::B_MVN) {
-      wg_solve_U(A, zz, P, 1, P);
-      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = zz[j] + mP[j];
-    } else {
-      for (int j = t; j < P; j += (int)blockDim.x) a.beta_out[j] = mP[j];
-    }
-    return;
   }
-
-  // S = PP^{-1}: two triangular solves on the identity
-  for (int e = t; e < P * P; e += (int)blockDim.x) S[e] = (e % P == e / P) ? 1.0 : 0.0;
   __syncthreads();
-  wg_solve_Ut(A, S, P, P, P, true);
-  wg_solve_U(A, S, P, P, P);
+  const View B{mP, 1, P};                  // columns: mP, eps
+  wg_trsm<false>(L, U, B, P, 0, 1);
+  wg_trsm<true>(L, U, B, P, 0, mode == blk::B_MVN ? 2 : 1);
+  if (mode == blk::B_MVN) {
+    for (int j = t; j < P; j += kDenseThreads) a.beta_out[j] = zz[j] + mP[j];
+  } else {
+    for (int j = t; j < P; j += kDenseThreads) a.beta_out[j] = mP[j];
+  }
+}
+
+// Stage 2 (a workgroup per 64 columns): S = PP^{-1} by two triangular solves on the identity and, for the constrained
+// draw, mP = PP^{-1} bP as column P of the same matrix (mP follows S in the workspace).  Columns are independent.
+__global__ __launch_bounds__(kDenseThreads) void k_beta_inverse(blk::BetaArgs a, int nc, int cpw)
+{
+  __shared__ DenseLds L;
+  if (*a.status & ST_NOT_PD) return;
+  const int P = a.P, t = threadIdx.x;
+  double* A = a.work;
+  double* S = a.work + (size_t)P * P;
+  const int c_lo = (int)blockIdx.x * cpw, c_hi = c_lo + cpw < nc ? c_lo + cpw : nc;
+  for (int e = t; e < (c_hi - c_lo) * P; e += kDenseThreads) {
+    const int i = e % P, c = c_lo + e / P;
+    S[(size_t)c * P + i] = c < P ? (i == c ? 1.0 : 0.0) : a.bP[i];
+  }
+  __syncthreads();
+  const View U{A, 1, P}, B{S, 1, P};
+  wg_trsm<false>(L, U, B, P, c_lo, c_hi);
+  wg_trsm<true>(L, U, B, P, c_lo, c_hi);
+}
+
+// The random input of the constrained sweeps for 64 < P <= 256 (independent of the matrices: any number of workgroups).
+__global__ __launch_bounds__(256) void k_beta_records(blk::BetaArgs a)
+{
+  constrained_wide_records(a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+
+// Stage 3 (one workgroup): L = chol(S, 'L') and what the draw needs of it.
+__global__ __launch_bounds__(kDenseThreads) void k_beta_finish(blk::BetaArgs a, int mode)
+{
+  __shared__ DenseLds L;
+  extern __shared__ double lds[];          // P > 256 constrained: beta, z (P each), perm
+  if (*a.status & ST_NOT_PD) return;
+  const int P = a.P, t = threadIdx.x;
+  double* A = a.work;                      // U
+  double* S = a.work + (size_t)P * P;      // PP^{-1}, then L
+  double* mP = a.work + 2 * (size_t)P * P; // posterior mean
+  double* zz = mP + P;
 
   if (mode == blk::B_FROM_LIK) {
     // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps   (Normal.hpp:98-131)
-    for (int i = t; i < P; i += (int)blockDim.x) {
+    for (int i = t; i < P; i += kDenseThreads) {
       double s = 0.0;
       for (int k2 = 0; k2 < P; ++k2) s += M_(S, i, k2) * a.bP[k2];
       mP[i] = s;
@@ -239,19 +369,25 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
     if (t < P) {
       Stream r;
       r.init(a.seed, 0, DOM_BETA, a.epoch);
-      for (int i = t; i < P; i += (int)blockDim.x) {
+      for (int i = t; i < P; i += kDenseThreads) {
         r.blk = (uint32_t)i;
         r.has = false;
         zz[i] = r.norm(0.0, 1.0);
       }
     }
     __syncthreads();
-    if (!wg_chol_lower(S, P, &bad)) {
-      __syncthreads();
-      if (t == 0) atomicOr(a.status, ST_NOT_PD);
-      return;
-    }
-    for (int i = t; i < P; i += (int)blockDim.x) {
+  }
+  if (!wg_chol(L, View{S, P, 1}, P)) {     // L = chol(S,'L'), in place
+    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    return;
+  }
+  for (int e = t; e < P * P; e += kDenseThreads) {
+    const int i = e % P, j = e / P;
+    if (i < j) S[e] = 0.0;
+  }
+  __syncthreads();
+  if (mode == blk::B_FROM_LIK) {
+    for (int i = t; i < P; i += kDenseThreads) {
       double le = 0.0;
       for (int k2 = 0; k2 <= i; ++k2) le += M_(S, i, k2) * zz[k2];
       a.beta_out[i] = le + mP[i];
@@ -259,40 +395,25 @@ __global__ __launch_bounds__(1024) void k_beta(blk::BetaArgs a, int mode)
     return;
   }
 
-  // ---- B_CONSTRAINED: Logit.hpp:322-400 ----
-  for (int j = t; j < P; j += (int)blockDim.x) mP[j] = a.bP[j];
+  // ---- B_CONSTRAINED: Logit.hpp:322-400 ----  z = L^{-1}(beta_prev - mP)
+  for (int j = t; j < P; j += kDenseThreads) zz[j] = a.beta_prev[j] - mP[j];
   __syncthreads();
-  wg_solve_Ut(A, mP, P, 1, P);
-  wg_solve_U(A, mP, P, 1, P);
-  if (!wg_chol_lower(S, P, &bad)) {     // L = chol(S,'L'), in place
-    __syncthreads();
-    if (t == 0) atomicOr(a.status, ST_NOT_PD);
-    return;
-  }
+  wg_trsm<false>(L, View{S, P, 1}, View{zz, 1, P}, P, 0, 1);
   if (P <= 256) {
-    // z = L^{-1}(beta_prev - mP), then the coordinate sweeps with their random input pre-generated
-    for (int j = t; j < P; j += (int)blockDim.x) zz[j] = a.beta_prev[j] - mP[j];
-    __syncthreads();
-    wg_solve_L(S, zz, P);
-    constrained_wide_prepare(a, S, A);      // U in A is dead: A takes 1/L.  k_beta_sweeps follows.
+    constrained_wide_reciprocals(a, S, A);  // U in A is dead: A takes 1/L.  The sweeps kernel follows.
     return;
   }
-  // LDS layout: beta, z (P doubles each), perm (P ints), then L (P*P) when it fits.  The vectors
-  // are exchanged between lanes of the serial wave, which LDS orders and global memory does not.
-  const bool l_in_lds = (size_t)P * P * 8 <= 128 * 1024;
+  // P > 256: LDS holds beta, z (P doubles each) and perm (P ints).  The vectors are exchanged between lanes of the
+  // serial wave, which LDS orders and global memory does not.
   double* sbeta = lds;
   double* sz = sbeta + P;
   int* perm = reinterpret_cast<int*>(sz + P);
-  double* Lm = l_in_lds ? sz + P + (P + 1) / 2 + 1 : S;
-  if (l_in_lds)
-    for (int e = t; e < P * P; e += (int)blockDim.x) Lm[e] = S[e];
+  const double* Lm = S;
   for (int j = t; j < P; j += (int)blockDim.x) {
-    zz[j] = a.beta_prev[j] - mP[j];     // z = beta_prev - mP
     sbeta[j] = a.beta_prev[j];
     perm[j] = j;
   }
   __syncthreads();
-  wg_solve_L(S, zz, P);                 // z = L^{-1} z
   for (int j = t; j < P; j += (int)blockDim.x) sz[j] = zz[j];
   __syncthreads();
 
@@ -1139,9 +1260,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 // (512 KB at P = 256: it lives in L2) next to its elementwise reciprocal; the columns of a move are fetched two
 // moves ahead, the records of the next scan are staged into LDS by the idle waves.
 // Scratch layout in a.work after the generic stage's 2 P^2 + 2 P doubles: records, then swap targets.
-__device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg)
+__device__ void constrained_wide_records(const blk::BetaArgs& a, int t, int nthr)
 {
-  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const int P = a.P;
   double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
   int* swp = reinterpret_cast<int*>(rec + (size_t)P * P * kRec);
   const uint32_t per_scan = (uint32_t)(10 * P - 1);
@@ -1166,6 +1287,12 @@ __device__ void constrained_wide_prepare(const blk::BetaArgs& a, const double* _
     R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
     R[17] = R[18] = R[19] = 0.0;
   }
+}
+
+__device__ void constrained_wide_reciprocals(const blk::BetaArgs& a, const double* __restrict__ Lg, double* Rg)
+{
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
   // 1/L elementwise, off the serial loop, split by the sign test of Logit.hpp:384-391: Rlo holds 1/L where
   // L > 0 (those rows bound the move from below), Rhi where L < 0, NaN elsewhere -- above the diagonal
   // (L = 0: rows j < c are outside the loop of :383) and in row P-1 (the loop stops at P-2).  v_max_f64 /
@@ -1707,18 +1834,22 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
     hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
     return;
   }
-  size_t lds = 0;
-  if (mode == B_CONSTRAINED) {
-    const size_t pp = (size_t)a.P * a.P * 8;
-    if (a.P <= 256)   // constrained_sweeps_wide: two scans of records, z, byte permutation table
-      lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;
-    else
-      lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8 + (pp <= 128 * 1024 ? pp : 0);
+  // P > 64: factor (one workgroup) -> inverse (a workgroup per 64 columns) -> finish (one workgroup) [-> sweeps]
+  const bool wide = mode == B_CONSTRAINED && a.P <= 256;
+  if (wide) hipLaunchKernelGGL(k_beta_records, dim3(64), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_beta_factor, dim3(1), dim3(kDenseThreads), 0, s, a, mode);
+  if (mode == B_SOLVE || mode == B_MVN) return;
+  {
+    const int nc = mode == B_CONSTRAINED ? a.P + 1 : a.P, cpw = 64;
+    hipLaunchKernelGGL(k_beta_inverse, dim3((nc + cpw - 1) / cpw), dim3(kDenseThreads), 0, s, a, nc, cpw);
   }
-  const bool wide = mode == B_CONSTRAINED && a.P <= 256;   // the dense stage then runs with its static LDS only
-  if (!wide && lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_beta, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_beta, dim3(1), dim3(a.P > 128 ? 1024 : 256), wide ? 0 : lds, s, a, mode);
+  size_t lds = 0;
+  if (mode == B_CONSTRAINED && !wide) {    // the serial sweeps of P > 256: beta, z, perm
+    lds = (2 * (size_t)a.P + (a.P + 1) / 2 + 1) * 8;
+    (void)hipFuncSetAttribute((const void*)k_beta_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  hipLaunchKernelGGL(k_beta_finish, dim3(1), dim3(kDenseThreads), lds, s, a, mode);
+  if (wide) lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;   // the one-wavefront sweeps' LDS
   if (wide && !beta_split_off()) {
     const size_t l2 = ((size_t)a.P + 32 + 128 + 4) * 8 + (size_t)a.P * a.P;
     const int nq = (a.P + 63) / 64;
