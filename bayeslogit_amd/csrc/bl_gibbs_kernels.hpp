@@ -31,9 +31,12 @@ SweepPlan make_plan(int64_t N, int P, int num_cus);
 //   off     : per-row offset subtracted from psi (mlogit c_j), or nullptr
 //   w_store : where omega_i is written (N doubles), or nullptr: `w_scratch` (N doubles)
 //             is used then (omega always passes through memory between the two passes).
+//   parts   : 1 = the psi/omega pass only, 2 = the X' Omega X pass only (omega as left in w), 3 = both
+//   xoc     : with parts == 2 and plan.fused == 1 (P <= 64): also xoc = X' Omega off (P doubles) from the same pass
 void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                   double* w_store, double* w_scratch, int64_t N, double* partial, double* PPpart, uint64_t seed,
-                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s);
+                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s, int parts = 3,
+                  double* xoc = nullptr);
 
 // out[j] = sum_i wgt_i x_ij, with wgt_i = n_i (y_i - 1/2) (kappa, Logit.hpp:174-183)
 // when w == nullptr, else wgt_i = w_i * c_i (c may be nullptr => 1).
@@ -46,8 +49,8 @@ void launch_colsum(const double* tX, const double* y, const double* n, const dou
 void launch_xbeta(const double* tX, const double* beta, int64_t N, int P, double* out, hipStream_t s);
 
 // mlogit: c_i = log sum_{k != j} exp(XB[i,k]) over the J columns of XB (N x J, last
-// column zero), MultLogit.hpp:293-299.
-void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, hipStream_t s);
+// column zero), MultLogit.hpp:293-299, and eta_i = XB[i,j] - c_i (:300).
+void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, double* eta_out, hipStream_t s);
 
 // ---- P x P stage (one workgroup; redundant on every rank) ----
 struct BetaArgs {

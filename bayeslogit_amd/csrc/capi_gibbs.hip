@@ -560,7 +560,7 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   const uint64_t seed = bl::chain_key(blh::global_seed(), blh::next_epoch());   // bl_philox.hpp
   hipStream_t s = nullptr;
   const size_t PPn = (size_t)p * p;
-  blh::DevBuf<double> dX, dty, dn, dw, dbeta, dXB, dc, dZ, db0, dP0, dm0, dkap, db1, dxoc;
+  blh::DevBuf<double> dX, dty, dn, dw, dbeta, dXB, dc, deta, done, dZ, db0, dP0, dm0, dkap, db1, dxoc;
   hipError_t e = dX.alloc((size_t)n * p);
   if (e == hipSuccess) e = dty.alloc((size_t)n * u);
   if (e == hipSuccess) e = dn.alloc(n);
@@ -568,6 +568,8 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   if (e == hipSuccess) e = dbeta.alloc((size_t)p * u * samp);
   if (e == hipSuccess) e = dXB.alloc((size_t)n * (u + 1));
   if (e == hipSuccess) e = dc.alloc(n);
+  if (e == hipSuccess) e = deta.alloc(n);
+  if (e == hipSuccess) e = done.alloc(1);
   if (e == hipSuccess) e = dZ.alloc((size_t)p * u);
   if (e == hipSuccess) e = db0.alloc((size_t)p * u);
   if (e == hipSuccess) e = dP0.alloc(PPn * u);
@@ -580,6 +582,8 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   if (e == hipSuccess) e = dn.upload(np);
   if (e == hipSuccess) e = dP0.upload(P0p);
   if (e == hipSuccess) e = dm0.upload(m0p);
+  const double one = 1.0;
+  if (e == hipSuccess) e = done.upload(&one);
   if (e == hipSuccess) e = hipMemset(dXB.p, 0, sizeof(double) * (size_t)n * (u + 1));
   if (e == hipSuccess) e = hipMemset(dbeta.p, 0, sizeof(double) * (size_t)p * u * samp);
   if (e != hipSuccess) {
@@ -600,6 +604,7 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
     blk::launch_colsum(dX.p, dyj.p, dn.p, nullptr, nullptr, n, p, h->colws, dZ.p + (size_t)j * p, s);
     blk::launch_matvec(db0.p + (size_t)j * p, dP0.p + (size_t)j * PPn, dm0.p + (size_t)j * p, p, s);   // b0_j = P0_j m0_j
   }
+  const blk::SweepPlan plan1 = blk::make_plan(n, 1, num_cus());
   const int total = burn + samp;   // burn+1 sweeps into slot 0, then samp-1 more (MultLogit.hpp:284,332)
   for (int sw = 0; rc == BL_OK && sw < total; ++sw) {
     const int slot = sw <= burn ? 0 : sw - burn;
@@ -610,10 +615,19 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
       double* bj = bslot + (size_t)j * p;
       // current beta_j lives in XB; the kernel needs beta_j itself: it is the last value written for j
       const double* bcur = (sw == 0) ? bj : (dbeta.p + (size_t)(sw <= burn ? 0 : slot - 1) * p * u + (size_t)j * p);
-      blk::launch_mlogit_offset(dXB.p, n, u + 1, j, dc.p, s);                       // c_j
-      blk::launch_sweep(h->plan, dX.p, dn.p, bcur, dc.p, wslot + (size_t)j * n, h->wscr, n, h->partial, h->PP, seed,
-                        epoch, 0, blk::W_DRAW, blh::status_word(s), s);             // eta = XB_j - c_j ; omega ; X'OmX
-      blk::launch_colsum(dX.p, nullptr, nullptr, wslot + (size_t)j * n, dc.p, n, p, h->colws, dxoc.p, s);   // X' Om c_j
+      // eta_j = XB_j - c_j from the stored XB, as MultLogit.hpp:293-300 has it (no pass over X); omega_j ~ PG(n, eta_j) by
+      // the sweep's own psi/omega pass run on eta as an N x 1 matrix with coefficient 1 (same stream keys as any sweep)
+      blk::launch_mlogit_offset(dXB.p, n, u + 1, j, dc.p, deta.p, s);
+      blk::launch_sweep(plan1, deta.p, dn.p, done.p, nullptr, wslot + (size_t)j * n, h->wscr, n, nullptr, nullptr, seed,
+                        epoch, 0, blk::W_DRAW, blh::status_word(s), s, 1);
+      if (h->plan.fused == 1) {                   // P <= 64: X' Om X and X' Om c_j from one pass over X
+        blk::launch_sweep(h->plan, dX.p, dn.p, nullptr, dc.p, wslot + (size_t)j * n, h->wscr, n, h->partial, h->PP, seed,
+                          epoch, 0, blk::W_DRAW, blh::status_word(s), s, 2, dxoc.p);
+      } else {
+        blk::launch_sweep(h->plan, dX.p, dn.p, nullptr, nullptr, wslot + (size_t)j * n, h->wscr, n, h->partial, h->PP,
+                          seed, epoch, 0, blk::W_DRAW, blh::status_word(s), s, 2);
+        blk::launch_colsum(dX.p, nullptr, nullptr, wslot + (size_t)j * n, dc.p, n, p, h->colws, dxoc.p, s);   // X' Om c_j
+      }
       blk::launch_vec_add(db1.p, dZ.p + (size_t)j * p, dxoc.p, p, s);
       blk::launch_vec_add(db1.p, db1.p, db0.p + (size_t)j * p, p, s);              // b1 = Z_j + X'Om c_j + b0_j
       blk::BetaArgs a;

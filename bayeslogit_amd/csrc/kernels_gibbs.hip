@@ -289,23 +289,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
 // ---- pass 2: PPpart = sum_i w_i x_i x_i'  on the fp64 matrix pipe    (Logit.hpp:294-301)
 // A wave streams 64-row tiles; per group of 4 rows the lane holds x(row k, colmap(q,c)) and
 // issues one v_mfma_f64_16x16x4_f64 per upper-triangle block pair (A = w x_qa, B = x_qb).
-template <int NB>
-struct Acc {
-  v4d a[NB * (NB + 1) / 2];
-};
-
-template <int NB, bool EXACT>
+// VEC (mlogit, MultLogit.hpp:246-247): X' Omega c in the same pass -- one more MFMA per block-row against an operand
+// whose only non-zero column is c (column 0 of NB extra accumulator blocks), instead of a second pass over X.
+template <int NB, bool EXACT, bool VEC>
 __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict__ tX, const double* __restrict__ w,
-                                                        int64_t N, int Pa, double* __restrict__ partial)
+                                                        const double* __restrict__ cvec, int64_t N, int Pa,
+                                                        double* __restrict__ partial)
 {
-  constexpr int NBLK = NB * (NB + 1) / 2;
+  constexpr int NBLK = NB * (NB + 1) / 2 + (VEC ? NB : 0);
   __shared__ double red[2][NBLK * 4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = lane >> 4, c = lane & 15;
   const int64_t ntiles = (N + 63) / 64;
   const int64_t W = (int64_t)gridDim.x * 4;
 
-  Acc<NB> acc;
+  struct {
+    v4d a[NBLK];
+  } acc;
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) acc.a[b] = v4d{0.0, 0.0, 0.0, 0.0};
 
@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
     }
     const int64_t myrow = tile * 64 + 4 * c + k;
     const double omega = myrow < N ? w[myrow] : 0.0;
+    const double cmy = (VEC && myrow < N) ? cvec[myrow] : 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const double wg = __shfl(omega, (lane & 48) | g);
@@ -332,6 +333,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
           acc.a[blkid] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], x[g][qb], acc.a[blkid], 0, 0, 0);
           ++blkid;
         }
+      if (VEC) {
+        const double cg = __shfl(cmy, (lane & 48) | g);
+        const double bv = c == 0 ? cg : 0.0;             // B[k][0] = c of row k of the group
+#pragma unroll
+        for (int qa = 0; qa < NB; ++qa)
+          acc.a[NB * (NB + 1) / 2 + qa] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[qa], bv, acc.a[NB * (NB + 1) / 2 + qa], 0, 0, 0);
+      }
     }
   }
 
@@ -368,11 +376,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_xwx_mfma(const double* __restrict
 
 // PP = sum over workgroups (fixed order) of the permuted MFMA blocks; un-permute,
 // take the i <= j half of diagonal blocks, mirror: PP is exactly symmetric.
-template <int NB>
+template <int NB, bool VEC>
 __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict__ partial, int nparts,
-                                                       double* __restrict__ PP, int Pa)
+                                                       double* __restrict__ PP, int Pa, double* __restrict__ xoc)
 {
-  constexpr int NBLK = NB * (NB + 1) / 2;
+  constexpr int NTRI = NB * (NB + 1) / 2;
+  constexpr int NBLK = NTRI + (VEC ? NB : 0);
   constexpr int E = NBLK * 4 * 64;
   __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -388,6 +397,11 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict_
 #pragma unroll
     for (int q = 1; q < 16; ++q) tot += sm[q][l];
     const int blkid = e / 256, reg = (e >> 6) & 3, ln = e & 63;
+    if (VEC && blkid >= NTRI) {                  // column 0 of block-row blkid - NTRI of X' Omega c
+      const int A = colmap<NB>(blkid - NTRI, (ln >> 4) + 4 * reg);
+      if ((ln & 15) == 0 && A < Pa) xoc[A] = tot;
+      return;
+    }
     int qa = 0, qb = 0, id = 0;
     for (int a = 0; a < NB; ++a)
       for (int b = a; b < NB; ++b) {
@@ -696,14 +710,16 @@ __global__ __launch_bounds__(kBlock) void k_xbeta(const double* __restrict__ tX,
 
 // MultLogit.hpp:293-299: A = rowSums(exp(XB_no_j)); c_j = log A
 __global__ __launch_bounds__(kBlock) void k_mlogit_offset(const double* __restrict__ XB, int64_t N, int J, int j,
-                                                          double* __restrict__ c_out)
+                                                          double* __restrict__ c_out, double* __restrict__ eta_out)
 {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
     double A = 0.0;
     for (int k = 0; k < J; ++k)
       if (k != j) A += exp(XB[(size_t)k * N + i]);
-    c_out[i] = log(A);
+    const double cj = log(A);
+    c_out[i] = cj;
+    eta_out[i] = XB[(size_t)j * N + i] - cj;        // eta_j = XB.col(j) - c_j, MultLogit.hpp:300
   }
 }
 
@@ -783,33 +799,45 @@ void launch_draw_pass(const blk::SweepPlan& plan, const double* tX, const double
 template <int NB, bool EXACT>
 void launch_nb_x(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                  double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
-                 int mode, int* status, hipStream_t s)
+                 int mode, int* status, hipStream_t s, int parts, double* xoc)
 {
   constexpr int E = NB * (NB + 1) / 2 * 4 * 64;
-  launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
-  hipLaunchKernelGGL((k_xwx_mfma<NB, EXACT>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, N, plan.P, partial);
-  hipLaunchKernelGGL((k_reduce_fused<NB>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP, plan.P);
+  if (parts & 1) launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  if (!(parts & 2)) return;
+  if (xoc) {
+    constexpr int EV = E + NB * 4 * 64;
+    hipLaunchKernelGGL((k_xwx_mfma<NB, EXACT, true>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, off, N, plan.P,
+                       partial);
+    hipLaunchKernelGGL((k_reduce_fused<NB, true>), dim3((EV + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP,
+                       plan.P, xoc);
+    return;
+  }
+  hipLaunchKernelGGL((k_xwx_mfma<NB, EXACT, false>), dim3(plan.nblocks), dim3(kBlock), 0, s, tX, w, nullptr, N, plan.P,
+                     partial);
+  hipLaunchKernelGGL((k_reduce_fused<NB, false>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PP,
+                     plan.P, nullptr);
 }
 template <int NB>
 void launch_nb(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0,
-               int mode, int* status, hipStream_t s)
+               int mode, int* status, hipStream_t s, int parts, double* xoc)
 {
   if (plan.P == 16 * NB)
-    launch_nb_x<NB, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+    launch_nb_x<NB, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s, parts, xoc);
   else
-    launch_nb_x<NB, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+    launch_nb_x<NB, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s, parts, xoc);
 }
 
 template <int NB, int NW, bool EXACT>
 void launch_nb_big_x(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
                      const double* off, double* w, int64_t N, double* partial, double* PP, uint64_t seed,
-                     uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+                     uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s, int parts)
 {
   constexpr int E = NB * (NB + 1) / 2 * 256;
   constexpr int P = 16 * NB;
   constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
-  launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  if (parts & 1) launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
+  if (!(parts & 2)) return;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_xwx_mfma_big<NB, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -823,12 +851,12 @@ void launch_nb_big_x(const blk::SweepPlan& plan, const double* tX, const double*
 template <int NB, int NW>
 void launch_nb_big(const blk::SweepPlan& plan, const double* tX, const double* n, const double* beta,
                    const double* off, double* w, int64_t N, double* partial, double* PP, uint64_t seed, uint32_t epoch,
-                   uint64_t idx0, int mode, int* status, hipStream_t s)
+                   uint64_t idx0, int mode, int* status, hipStream_t s, int parts)
 {
   if (plan.P == 16 * NB)
-    launch_nb_big_x<NB, NW, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+    launch_nb_big_x<NB, NW, true>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s, parts);
   else
-    launch_nb_big_x<NB, NW, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s);
+    launch_nb_big_x<NB, NW, false>(plan, tX, n, beta, off, w, N, partial, PP, seed, epoch, idx0, mode, status, s, parts);
 }
 
 }  // namespace
@@ -876,7 +904,7 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     if (nb > 2 * (int64_t)num_cus) nb = 2 * (int64_t)num_cus;   // pass 2: two 4-wave workgroups per CU
     p.nblocks = (int)nb;
     plan_draw_pass(p, N, num_cus);
-    p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 4 * 64;
+    p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2 + p.nb) * 4 * 64;   // + the X' Omega c blocks of mlogit
   } else {
     p.fused = 0;
     const int T = (P + 63) / 64;
@@ -892,33 +920,35 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
 
 void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, const double* beta, const double* off,
                   double* w_store, double* w_scratch, int64_t N, double* partial, double* PPpart, uint64_t seed,
-                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s)
+                  uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s, int parts, double* xoc)
 {
   const int P = plan.P;
   double* w = w_store ? w_store : w_scratch;
   if (plan.fused == 2) {
     if (plan.nb == 8)
-      launch_nb_big<8, 4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+      launch_nb_big<8, 4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts);
     else
-      launch_nb_big<16, 8>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+      launch_nb_big<16, 8>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts);
     return;
   }
   if (plan.fused) {
     switch (plan.nb) {
-      case 1: launch_nb<1>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      case 2: launch_nb<2>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      case 3: launch_nb<3>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s); break;
-      default: launch_nb<4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s);
+      case 1: launch_nb<1>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts, xoc); break;
+      case 2: launch_nb<2>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts, xoc); break;
+      case 3: launch_nb<3>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts, xoc); break;
+      default: launch_nb<4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts, xoc);
     }
     return;
   }
   const int g = grid_for(N, kBlock, 256 * 8);
-  if (mode == W_DRAW)
+  if (!(parts & 1)) {
+  } else if (mode == W_DRAW)
     hipLaunchKernelGGL((k_psi_omega<W_DRAW>), dim3(g), dim3(kBlock), sizeof(double) * P, s, tX, n, beta, off, w, N, P,
                        seed, epoch, idx0, status);
   else
     hipLaunchKernelGGL((k_psi_omega<W_EM>), dim3(g), dim3(kBlock), sizeof(double) * P, s, tX, n, beta, off, w, N, P,
                        seed, epoch, idx0, status);
+  if (!(parts & 2)) return;
   const int T = (P + 63) / 64;
   int64_t rpc = (N + plan.nblocks - 1) / plan.nblocks;
   rpc = (rpc + kRows - 1) / kRows * kRows;
@@ -956,10 +986,10 @@ void launch_xbeta(const double* tX, const double* beta, int64_t N, int P, double
                      out);
 }
 
-void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, hipStream_t s)
+void launch_mlogit_offset(const double* XB, int64_t N, int J, int j, double* c_out, double* eta_out, hipStream_t s)
 {
   if (N <= 0) return;
-  hipLaunchKernelGGL(k_mlogit_offset, dim3(grid_for(N, kBlock, 256 * 8)), dim3(kBlock), 0, s, XB, N, J, j, c_out);
+  hipLaunchKernelGGL(k_mlogit_offset, dim3(grid_for(N, kBlock, 256 * 8)), dim3(kBlock), 0, s, XB, N, J, j, c_out, eta_out);
 }
 
 void launch_welford(const double* x, double* mean, double* m2, int64_t n, int64_t count, hipStream_t s)
