@@ -32,7 +32,8 @@ def shard_of(X, y, n, gpu, seed, idx0=0):
 
 
 @pytest.mark.parametrize("N,P", [(1000, 64), (64, 64), (65, 64), (4097, 32), (777, 16), (300, 48), (1500, 48),
-                                 (500, 10), (200, 1), (333, 70), (2000, 70), (150, 130), (2600, 130), (20000, 130), (3000, 128), (1001, 256), (17, 128)])
+                                 (500, 10), (200, 1), (333, 70), (2000, 70), (150, 130), (2600, 130), (20000, 130), (3000, 128), (1001, 256), (17, 128),
+                                 (900, 97), (2500, 200), (3200, 300)])
 def test_one_sweep_matches_oracle(gpu, oracle, N, P):
     """fused MFMA path (P in 16,32,48,64) and the generic path (other P), ragged N included."""
     from bayeslogit_amd import device as D
@@ -294,6 +295,30 @@ def test_mlogit_matches_oracle(gpu, oracle):
     assert np.allclose(out["w"], wo, rtol=1e-6, atol=0)
     yc = bl.mlogit_combine(np.repeat(y[:50], 2, axis=0), np.repeat(X[:50], 2, axis=0))
     assert yc["X"].shape == (50, P) and np.all(yc["n"] == 2)
+
+
+def test_mlogit_wide_design_matches_oracle(gpu, oracle):
+    """P = 70: the P x P stage of every category runs on the blocked factor / inverse / finish kernels
+    (Normal::set_from_likelihood, include/Normal.hpp:98-131) and X' Omega c_j on the column-sum pass."""
+    import bayeslogit_amd as bl
+    rng = np.random.default_rng(19)
+    N, P, J = 1500, 70, 3
+    X = rng.normal(size=(N, P)) / 6
+    X[:, -1] = 1.0
+    B = rng.normal(size=(P, J - 1)) * 0.4
+    eta = np.concatenate([X @ B, np.zeros((N, 1))], axis=1)
+    pr = np.exp(eta) / np.exp(eta).sum(1, keepdims=True)
+    cat = np.array([rng.choice(J, p=p) for p in pr])
+    y = np.zeros((N, J - 1))
+    for j in range(J - 1):
+        y[cat == j, j] = 1.0
+    m0 = np.zeros((P, J - 1))
+    P0 = np.repeat((np.eye(P) * 0.5)[:, :, None], J - 1, axis=2)
+    bl.set_seed(77)
+    out = bl.mlogit(y, X, None, m0, P0, samp=2, burn=1)
+    wo, bo = oracle.mult_gibbs(y, X, np.ones(N), m0, P0, 2, 1, oracle.chain_key(77, 0))
+    assert np.allclose(out["beta"], bo, rtol=1e-7, atol=1e-8), np.abs(out["beta"] - bo).max()
+    assert np.allclose(out["w"], wo, rtol=1e-6, atol=0)
 
 
 def test_mlogit_large_many_categories(gpu, oracle):
