@@ -38,6 +38,13 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
                   uint32_t epoch, uint64_t idx0, int mode, int* status, hipStream_t s, int parts = 3,
                   double* xoc = nullptr);
 
+// The same sweep with X read once (kernels_sweep1.hip): P = 64, W_DRAW, no offset.  launch_sweep takes this path
+// when sweep_single_pass() is on (default; bl_set_sweep_mode) and the call is eligible; same omega bit for bit,
+// PPpart in another (fixed) summation order.  stats (or nullptr): += the number of rows that left the fast path.
+void launch_sweep_once64(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
+                         double* partial, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
+                         unsigned long long* stats, hipStream_t s);
+
 // out[j] = sum_i wgt_i x_ij, with wgt_i = n_i (y_i - 1/2) (kappa, Logit.hpp:174-183)
 // when w == nullptr, else wgt_i = w_i * c_i (c may be nullptr => 1).
 // ws: workspace of colsum_ws_doubles(N, P) doubles.

@@ -24,6 +24,8 @@ int launch_rpg_tasks(bool sp, double* x, const double* h, const double* z, int64
 uint64_t global_seed();
 uint32_t next_epoch();                      // returns current, then increments
 int      global_constrain();
+int      sweep_single_pass();               // bl_set_sweep_mode / BL_SWEEP_SINGLE_PASS (default 1)
+unsigned long long* sweep_stats();          // device counters of the single-pass sweep (bl_diag_sweep_deferred)
 
 #define BL_HIP_TRY(expr)                                                            \
   do {                                                                              \

@@ -187,6 +187,47 @@ BL_HD bool pg1_decide(Pg1Lane& s, double X, double A, double rarg, double u2, in
   return ok;
 }
 
+// The exponential piece (right) and the mu > t left piece share one body -- one log, one divide, one exp: the
+// proposal X (:171 / :98-99), the threshold A of u2 (1 on the right) and log(a_1/a_0) - log 3 at X.
+template <bool FAST>
+BL_HD void pg1_small_body(bool right, double w, double Z, double fz, double& X, double& A, double& rarg)
+{
+  const double E = -(FAST ? bl_log(w) : log(w));
+  const double d = 1.0 + kSmT * E;
+  const double q = FAST ? bl_div(right ? E : kSmT, right ? fz : d * d) : (right ? E / fz : kSmT / (d * d));
+  X = right ? kSmT + q : q;
+  const double aarg = -0.5 * (kSmT * E * E + Z * Z * X);
+  A = right ? 1.0 : (FAST ? bl_exp(aarg) : exp(aarg));
+  rarg = right ? -kSmPiSq * X : -(4.0 / kSmT) * d * d;
+}
+
+// One attempt of a |z|/2 < 1/t observation (finite z) whose state is KNOWN to the caller, without the rare
+// path: the same arithmetic and the same tests as pg1_attempt<FAST, 1> + pg1_decide up to the first series
+// test.  Returns 0: u2 > A, the next attempt is a retry inside the left piece; 1: accepted, the draw is
+// 0.25 X; 2: the first series test failed (about 8e-4 of proposals) -- pg1_attempt would walk the series;
+// a caller that evaluates attempts ahead of time (the single-pass Gibbs sweep: lanes a = 0..3 of a row take
+// blocks 0..3, block 0 fresh and the others as retries) hands such an observation to the full sampler, which
+// replays its stream from block 0.
+template <bool FAST = true>
+BL_HD int pg1_attempt_small_known(bool fresh, double Z, double fz, double mass, double u1, double u2, double& X)
+{
+  const bool right = fresh && u1 < mass;                                         // :170
+  // u1 im resp. (u1 - mass) il of pg1_attempt with the one reciprocal that is used
+  const double inv = bl_div(1.0, right ? mass : 1.0 - mass);                     // pg1_par_finish
+  double w = fresh ? (right ? u1 : u1 - mass) * inv : u1;
+  w = w < kSmWMin ? kSmWMin : w;
+  w = w > kSmWMax ? kSmWMax : w;
+  double A, rarg;
+  pg1_small_body<FAST>(right, w, Z, fz, X, A, rarg);
+  const bool inner = !(u2 > A);
+  bool ok = u2 <= A * (1.0 - kSmRatioMax);
+  if (pg1_any(inner && !ok)) {
+    const double r3 = 3.0 * (FAST ? bl_exp(rarg) : exp(rarg));
+    ok = ok || u2 <= A * (1.0 - r3);
+  }
+  return inner ? (ok ? 1 : 2) : 0;
+}
+
 // One attempt: consume the block (u1, u2).  Returns true when a draw has completed; the draw is
 // then 0.25 * lane.X and the lane is ready for the next one.
 // FAST: bl_fastmath log/exp (default) or libm's.
@@ -203,14 +244,8 @@ BL_HD bool pg1_attempt(Pg1Lane& s, const Pg1Par& p, double u1, double u2, int& s
   const bool small = ZC == 1 || (ZC == 0 && kSmTRecip > p.Z);                    // :87, mu > t
 
   if (ZC != 2 && (right || small)) {
-    // exponential piece and the mu > t left piece share one body: one log, one divide, one exp
-    const double E = -(FAST ? bl_log(w) : log(w));
-    const double d = 1.0 + kSmT * E;
-    const double q = FAST ? bl_div(right ? E : kSmT, right ? p.fz : d * d) : (right ? E / p.fz : kSmT / (d * d));
-    const double X = right ? kSmT + q : q;                                       // :171 / :98-99
-    const double aarg = -0.5 * (kSmT * E * E + p.Z * p.Z * X);
-    const double A = right ? 1.0 : (FAST ? bl_exp(aarg) : exp(aarg));
-    const double rarg = right ? -kSmPiSq * X : -(4.0 / kSmT) * d * d;            // log(a_1/a_0) - log 3
+    double X, A, rarg;
+    pg1_small_body<FAST>(right, w, p.Z, p.fz, X, A, rarg);
     return pg1_decide<FAST>(s, X, A, rarg, u2, status);
   }
   if (right) {                                                                   // ZC == 2 only

@@ -351,9 +351,10 @@ int bl_gibbs_run_stream(bl_gibbs* h, int samp, int burn, int constrain, int thin
       wdst = w_out;
     }
     if (e != hipSuccess) break;
+    if (!wdst && wstats) wdst = h->wscr;               // the moments read omega; a sweep stores it only on request
     rc = bl_gibbs_sweep_local(h, sweep, wdst);
     if (rc != BL_OK) break;
-    const double* wsrc = wdst ? wdst : h->wscr;                               // where this sweep's omega is
+    const double* wsrc = wdst;                                                // where this sweep's omega is
     if (wstats) blk::launch_welford(wsrc, stats->w_mean_dev, stats->w_var_dev, N, m + 1, h->stream);
     if (w_mode == BL_W_ALL && N > 0) {
       e = hipEventRecord(ev_done[slot], h->stream);

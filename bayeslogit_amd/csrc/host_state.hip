@@ -18,6 +18,13 @@ uint64_t initial_seed()
 std::atomic<uint64_t> g_seed{initial_seed()};
 std::atomic<uint32_t> g_epoch{0};
 std::atomic<int> g_constrain{1};
+int initial_sweep_mode()
+{
+  if (const char* s = getenv("BL_SWEEP_SINGLE_PASS")) return atoi(s) ? 1 : 0;
+  return 1;
+}
+std::atomic<int> g_sweep_mode{initial_sweep_mode()};
+unsigned long long* g_sweep_stats_dev = nullptr;     // [0] rows that left the single-pass sweep's fast path
 int* g_status_dev = nullptr;
 bool g_dev_ok = false, g_dev_tried = false;
 }  // namespace
@@ -45,6 +52,8 @@ bool ensure_device()
   }
   e = hipMalloc((void**)&g_status_dev, sizeof(int));
   if (e == hipSuccess) e = hipMemset(g_status_dev, 0, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&g_sweep_stats_dev, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(g_sweep_stats_dev, 0, 16 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     g_err = std::string("hipMalloc(status): ") + hipGetErrorString(e);
     fprintf(stderr, "bayeslogit_hip: %s\n", g_err.c_str());
@@ -85,6 +94,8 @@ int collect_status(hipStream_t s)
 uint64_t global_seed() { return g_seed.load(); }
 uint32_t next_epoch() { return g_epoch.fetch_add(1); }
 int global_constrain() { return g_constrain.load(); }
+int sweep_single_pass() { return g_sweep_mode.load(); }
+unsigned long long* sweep_stats() { return g_sweep_stats_dev; }
 
 }  // namespace blh
 
@@ -138,6 +149,23 @@ void bl_set_seed_from_unif(double* u)
 uint32_t bl_get_epoch(void) { return g_epoch.load(); }
 void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
 void bl_set_constrain_R(int* c) { g_constrain = (c && *c) ? 1 : 0; }
+void bl_set_sweep_mode(int single_pass) { g_sweep_mode = single_pass ? 1 : 0; }
+int bl_diag_sweep_deferred(uint64_t* rows)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  unsigned long long v[16] = {0};
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(v, g_sweep_stats_dev, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemset(g_sweep_stats_dev, 0, sizeof(v)) != hipSuccess) {
+    blh::set_error("bl_diag_sweep_deferred: HIP call failed");
+    return BL_ERR_HIP;
+  }
+  if (rows) *rows = v[0];
+  if (v[7])      // development build of the kernel (BL_SWEEP1_VARIANT=3): per-wave phase stamps
+    fprintf(stderr, "sweep1 stamps per wave (shader cycles): load wait %.0f, psi+attempt %.0f, mfma issue %.0f, kernel %.0f; clock %.0f MHz\n",
+            (double)v[2] / v[7], (double)v[3] / v[7], (double)v[4] / v[7], (double)v[5] / v[7], 100.0 * v[5] / (double)v[6]);
+  return BL_OK;
+}
 void bl_set_device_R(int* device, int* rc)
 {
   const int r = bl_set_device(device ? *device : 0);

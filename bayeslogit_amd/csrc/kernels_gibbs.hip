@@ -15,6 +15,7 @@
 //   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
 #include "bl_gibbs_kernels.hpp"
+#include "bl_host.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_queue.hpp"
 #include "../../include/bayeslogit_hip.h"
@@ -929,6 +930,15 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
       launch_nb_big<8, 4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts);
     else
       launch_nb_big<16, 8>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts);
+    return;
+  }
+  if (plan.fused == 1 && plan.P == 64 && mode == W_DRAW && !off && parts == 3 && !xoc && N > 0 &&
+      blh::sweep_single_pass()) {
+    // X read once (kernels_sweep1.hip); omega is stored only if the caller wants it
+    constexpr int E = 10 * 4 * 64;
+    launch_sweep_once64(plan.nblocks, tX, n, beta, w_store, N, partial, seed, epoch, idx0, status, blh::sweep_stats(), s);
+    hipLaunchKernelGGL((k_reduce_fused<4, false>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PPpart,
+                       plan.P, nullptr);
     return;
   }
   if (plan.fused) {

@@ -130,6 +130,12 @@ int bl_fill_shape_dev(double *out, int64_t num, int kmax,
  * performs (the caller times it with events on `stream`).  work: >= CUs * waves_per_simd * 256 doubles. */
 int bl_diag_mfma_f64_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
                          void *stream);
+/* The Gibbs sweep over a rank's rows (Logit.hpp:283-301,431: psi = X beta, omega ~ PG(n, psi), X' Omega X) reads X
+ * once when P = 64 (single_pass = 1, the default; env BL_SWEEP_SINGLE_PASS) or in two streaming passes
+ * (single_pass = 0; every other P).  Same omega bit for bit; X' Omega X in another, equally fixed, summation order.
+ * bl_diag_sweep_deferred: rows the single-pass kernel handed to the full sampler since the last call (a sync). */
+void bl_set_sweep_mode(int single_pass);
+int  bl_diag_sweep_deferred(uint64_t *rows);
 /* y[i] ~ Bernoulli(sigmoid(x_i . beta)) for a P x N column-major tX */
 int bl_fill_logit_y_dev(double *y, const double *tX, const double *beta, int64_t N, int P,
                         uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);
