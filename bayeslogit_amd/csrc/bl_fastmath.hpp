@@ -76,12 +76,11 @@ BL_HD double bl_log(double x)
   return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
-BL_HD double bl_exp(double x)
+// exp(x) for -708 <= x <= 709.78 (no range checks)
+BL_HD double bl_exp_core(double x)
 {
   constexpr double inv_ln2 = 1.44269504088896338700e+00;
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  if (x < -708.0) return 0.0;   // below: results would be subnormal; the samplers treat them as 0
-  if (x > 709.78) return __builtin_huge_val();
   // k = round(x / ln 2) by the 1.5 * 2^52 trick: the integer lands in the low mantissa bits
   const double shifted = x * inv_ln2 + 0x1.8p52;
   const double kd = shifted - 0x1.8p52;
@@ -110,6 +109,22 @@ BL_HD double bl_exp(double x)
   double out;
   memcpy(&out, &pb, 8);
   return out;
+}
+
+BL_HD double bl_exp(double x)
+{
+  if (x < -708.0) return 0.0;   // below: results would be subnormal; the samplers treat them as 0
+  if (x > 709.78) return __builtin_huge_val();
+  return bl_exp_core(x);
+}
+
+// bl_exp as straight-line code (selects instead of the two early returns; same values): for callers that
+// interleave it with matrix instructions inside one basic block
+BL_HD double bl_exp_straight(double x)
+{
+  const bool lo = x < -708.0, hi = x > 709.78;
+  const double r = bl_exp_core((lo || hi) ? 0.0 : x);
+  return lo ? 0.0 : (hi ? __builtin_huge_val() : r);
 }
 
 }  // namespace bl

@@ -202,30 +202,54 @@ BL_HD void pg1_small_body(bool right, double w, double Z, double fz, double& X, 
 }
 
 // One attempt of a |z|/2 < 1/t observation (finite z) whose state is KNOWN to the caller, without the rare
-// path: the same arithmetic and the same tests as pg1_attempt<FAST, 1> + pg1_decide up to the first series
-// test.  Returns 0: u2 > A, the next attempt is a retry inside the left piece; 1: accepted, the draw is
-// 0.25 X; 2: the first series test failed (about 8e-4 of proposals) -- pg1_attempt would walk the series;
-// a caller that evaluates attempts ahead of time (the single-pass Gibbs sweep: lanes a = 0..3 of a row take
-// blocks 0..3, block 0 fresh and the others as retries) hands such an observation to the full sampler, which
-// replays its stream from block 0.
-template <bool FAST = true>
+// path and without a branch: the arithmetic and the tests of pg1_attempt<true, 1> + pg1_decide up to the first
+// series test, in STAGES, so that a caller can put other work between them (the single-pass Gibbs sweep issues
+// its matrix instructions there).  Verdict 0: u2 > A, the next attempt is a retry inside the left piece; 1:
+// accepted, the draw is 0.25 X; 2: the first series test failed (about 8e-4 of proposals) -- pg1_attempt would
+// walk the series.  A caller that evaluates attempts ahead of time (lanes a = 0..3 of a row take blocks 0..3,
+// block 0 fresh and the others as retries) hands such an observation to the full sampler, which replays its
+// stream from block 0.
+struct Pg1Staged {
+  bool right;
+  double w, E, d, X, aarg, rarg, A, r3;
+};
+// :170 and the proposal's uniform: u1 im resp. (u1 - mass) il of pg1_attempt, with the one reciprocal that is used
+BL_HD void pg1_stage_w(Pg1Staged& s, bool fresh, double mass, double u1)
+{
+  s.right = fresh && u1 < mass;
+  const double inv = bl_div(1.0, s.right ? mass : 1.0 - mass);                   // pg1_par_finish
+  double w = fresh ? (s.right ? u1 : u1 - mass) * inv : u1;
+  w = w < kSmWMin ? kSmWMin : w;
+  s.w = w > kSmWMax ? kSmWMax : w;
+}
+BL_HD void pg1_stage_log(Pg1Staged& s) { s.E = -bl_log(s.w); }
+BL_HD void pg1_stage_x(Pg1Staged& s, double Z, double fz)
+{
+  s.d = 1.0 + kSmT * s.E;
+  const double q = bl_div(s.right ? s.E : kSmT, s.right ? fz : s.d * s.d);
+  s.X = s.right ? kSmT + q : q;
+  s.aarg = -0.5 * (kSmT * s.E * s.E + Z * Z * s.X);
+  s.rarg = s.right ? -kSmPiSq * s.X : -(4.0 / kSmT) * s.d * s.d;
+}
+// exp(0) is exactly 1: no select on the result, so the exponential is not sunk into a branch
+BL_HD void pg1_stage_A(Pg1Staged& s) { s.A = bl_exp_straight(s.right ? 0.0 : s.aarg); }
+BL_HD void pg1_stage_r3(Pg1Staged& s) { s.r3 = 3.0 * bl_exp_straight(s.rarg); }   // a_1/a_0, whether or not the lane needs it
+BL_HD int pg1_stage_verdict(const Pg1Staged& s, double u2)
+{
+  const bool inner = !(u2 > s.A);
+  const bool ok = u2 <= s.A * (1.0 - kSmRatioMax) || u2 <= s.A * (1.0 - s.r3);
+  return inner ? (ok ? 1 : 2) : 0;
+}
 BL_HD int pg1_attempt_small_known(bool fresh, double Z, double fz, double mass, double u1, double u2, double& X)
 {
-  const bool right = fresh && u1 < mass;                                         // :170
-  // u1 im resp. (u1 - mass) il of pg1_attempt with the one reciprocal that is used
-  const double inv = bl_div(1.0, right ? mass : 1.0 - mass);                     // pg1_par_finish
-  double w = fresh ? (right ? u1 : u1 - mass) * inv : u1;
-  w = w < kSmWMin ? kSmWMin : w;
-  w = w > kSmWMax ? kSmWMax : w;
-  double A, rarg;
-  pg1_small_body<FAST>(right, w, Z, fz, X, A, rarg);
-  const bool inner = !(u2 > A);
-  bool ok = u2 <= A * (1.0 - kSmRatioMax);
-  if (pg1_any(inner && !ok)) {
-    const double r3 = 3.0 * (FAST ? bl_exp(rarg) : exp(rarg));
-    ok = ok || u2 <= A * (1.0 - r3);
-  }
-  return inner ? (ok ? 1 : 2) : 0;
+  Pg1Staged s;
+  pg1_stage_w(s, fresh, mass, u1);
+  pg1_stage_log(s);
+  pg1_stage_x(s, Z, fz);
+  pg1_stage_A(s);
+  pg1_stage_r3(s);
+  X = s.X;
+  return pg1_stage_verdict(s, u2);
 }
 
 // One attempt: consume the block (u1, u2).  Returns true when a draw has completed; the draw is

@@ -33,6 +33,27 @@ BL_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
   return U4{c0, c1, c2, c3};
 }
 
+// The same block function a few rounds at a time, for a caller that puts other work between the rounds:
+// philox_rounds(s, 10) on s = {ctr, key} leaves philox4x32_10(ctr, key) in s.c.
+struct PhiloxState { U4 c; uint32_t k0, k1; };
+template <int R>
+BL_HD void philox_rounds(PhiloxState& s)
+{
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * s.c.x;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * s.c.z;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ s.c.y ^ s.k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ s.c.w ^ s.k1;
+    s.c.y = (uint32_t)p1;
+    s.c.w = (uint32_t)p0;
+    s.c.x = n0;
+    s.c.z = n2;
+    s.k0 += 0x9E3779B9u;
+    s.k1 += 0xBB67AE85u;
+  }
+}
+
 // (m + 1/2) 2^-52 for the 52-bit integer m = (hi:lo) >> 12, built without an int->fp conversion:
 // 1.m (exponent 0 | mantissa m) minus 1 is m 2^-52 exactly, and adding 2^-53 is exact too
 // (2m+1 < 2^53), so this is bit-for-bit ((double)m + 0.5) * 2^-52.

@@ -3,31 +3,39 @@
 //   psi = X beta, omega_i ~ PG(n_i, psi_i), PPpart = sum_i omega_i x_i x_i'      (Logit.hpp:283-301,431)
 //
 // kernels_gibbs.hip does this in two streaming passes (psi/omega, then X' Omega X) because the draw's work
-// queue wants hundreds of rows per wave while the rows wait on chip.  Here a wave takes 16 rows at a time --
-// 8 KB, 32 registers per lane, the next tile's loads in flight in 32 more -- and removes the queue instead:
+// queue wants hundreds of rows per wave while the rows wait on chip.  Here a wave takes 16 rows at a time and
+// removes the queue instead:
 //
+//   * tiles travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers hold data in flight), already in
+//     MFMA operand order (piece (g, h) = lane (k, c)'s 16 bytes of row 4g+k, columns 32h+2c, 32h+2c+1), two
+//     8 KB slots per wave: while tile t is in registers for its MFMAs and tile t+1 is in its slot, tile t+2 is
+//     on its way into the slot tile t has just left;
 //   * the four lanes (k, 4g .. 4g+3) of an MFMA operand row all receive psi of row 4g+k from the 16-lane
 //     butterfly anyway; lane a = 0..3 of that quad evaluates ATTEMPT a of the row's draw (Philox block a of the
 //     row's stream) ahead of time: attempt 0 as a fresh proposal, attempts 1..3 as retries inside the left
 //     piece -- which is what they are whenever they are reached at all: a fresh proposal is rejected by the
 //     inner test of the mu > t inverse-Gaussian piece (u2 > A, PolyaGamma.cpp:89-101) in 14-26 % of the cases
-//     and by the alternating series in < 0.6 %.  The first accepting attempt in block order is the draw, bit
-//     for bit what the work queue of pass 1 returns (same blocks, same arithmetic: pg1_attempt_small_known);
-//   * one attempt body per tile, no loop: a row that is not settled by its four attempts (0.3-2 %), or whose
-//     first series test fails (8e-4), or with |psi|/2 >= 1/t (the other left-piece sampler), or with n_i != 1,
-//     is DEFERRED: it enters this tile's MFMAs with weight 0 and goes to a per-wave list; every 16 deferred
-//     rows are drawn by the full sampler (pg1_draw_n, out of line), their rows of X gathered again (L2 / HBM:
-//     1-5 % extra traffic) and added by four more MFMA groups;
-//   * the tile then goes through the fp64 matrix pipe exactly as in k_xwx_mfma (same lane <-> column
-//     assignment, A = omega x_qa, B = x_qb, ten upper-triangle blocks): no LDS, no barrier, no other wave.
+//     and by the alternating series in < 0.6 %.  The first accepting attempt in block order is the draw -- the
+//     value the work queue of pass 1 returns (same blocks, same arithmetic: pg1_attempt_small_known);
+//   * one attempt body per tile, no loop, no branch: a row that is not settled by its four attempts (0.3-2 %),
+//     or whose first series test fails (8e-4), or with |psi|/2 >= 1/t (the other left-piece sampler), or with
+//     n_i != 1, is DEFERRED: it enters its tile's MFMAs with weight 0 and goes to a per-wave list; every 16
+//     deferred rows are drawn by the full sampler (pg1_draw_n, out of line), their rows of X gathered again
+//     (L2 / HBM: 1-5 % extra traffic) and added by four more MFMA groups;
+//   * SOFTWARE PIPELINE: the attempt body of tile t+1 (about 450 vector instructions) and the 40
+//     v_mfma_f64_16x16x4_f64 of tile t (same lane <-> column assignment as k_xwx_mfma, A = omega x_qa, B = x_qb,
+//     ten upper-triangle blocks) are one basic block, interleaved by the scheduler (sched_group_barrier: one
+//     matrix instruction, then eleven vector instructions), so that every wave keeps the matrix pipe and the
+//     vector ALU busy at the same time whatever its SIMD partner is doing.  (Un-pipelined -- body, then MFMAs --
+//     the two waves of a SIMD fall into step, both in their matrix phase or both in their vector phase:
+//     1.53 ms per C4 sweep against 1.87 for the two passes; stamps in DESIGN.md.)
 //
-// Two waves per SIMD: one wave's attempt body (VALU) runs beside the other's MFMAs.  omega and psi are the
-// values of the two-pass kernels bit for bit; PP differs from theirs in summation order only (fixed order:
+// Two waves per SIMD.  psi and omega are those of the two-pass kernels (omega to the last bits: the full
+// sampler is another instantiation of the same header); PP differs in summation order only (fixed order:
 // reproducible).  Slab layout and reduction are k_xwx_mfma's (k_reduce_fused).
 #include "bl_gibbs_kernels.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_sm.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -37,27 +45,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;
 constexpr int kDefCap = 32;      // a tile adds at most 16 entries to a list of at most 15
-
-struct Tile {
-  v2d v[4][2];     // group g (rows 4g .. 4g+3), half h: columns 32h + 2c, 32h + 2c + 1 of row 4g + k
-  double nn;       // n of this lane's row (row 4 (c >> 2) + k)
-};
-
-// rows >= r1 (the end of the wave's range) read the range's last row; their weight is 0
-__device__ __forceinline__ void tile_load(Tile& T, const double* __restrict__ tX, const double* __restrict__ nvec,
-                                          int64_t base, int64_t r1, int k, int c)
-{
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int64_t row = base + 4 * g + k;
-    const double* p = tX + (size_t)(row < r1 ? row : r1 - 1) * 64;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      T.v[g][h] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + 32 * h + 2 * c));
-  }
-  const int64_t myrow = base + 4 * (c >> 2) + k;
-  T.nn = __builtin_nontemporal_load(nvec + (myrow < r1 ? myrow : r1 - 1));
-}
 
 // the full sampler for a deferred row (any class, any n): the observation's stream from block 0
 __device__ __attribute__((noinline)) double draw_full(int n, double psi, uint64_t seed, uint64_t idx, uint32_t epoch,
@@ -88,7 +75,20 @@ __device__ __forceinline__ void mfma_group(v4d (&acc)[10], const double (&x)[4],
     }
 }
 
-template <int VAR>
+// s_waitcnt vmcnt(n) lgkmcnt(no wait) expcnt(no wait), n <= 15
+#define BL_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
+
+// MFMAs K0 .. K1-1 of a tile's 40 (number 10 g + b: group g, upper-triangle block b = (qa, qb)), fenced on both sides
+__device__ constexpr int kQa[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, kQb[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+#define BL_MFMAS(K0, K1)                                                                                         \
+  do {                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int kk = (K0); kk < (K1); ++kk)                                                       \
+      acc[kk % 10] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[kk / 10][kQa[kk % 10]], xm[kk / 10][kQb[kk % 10]],   \
+                                                           acc[kk % 10], 0, 0, 0);                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  } while (0)
+
 __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __restrict__ tX,
                                                             const double* __restrict__ nvec,
                                                             const double* __restrict__ beta, double* __restrict__ w,
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
                                                             unsigned long long* __restrict__ stats)
 {
   constexpr int NBLK = 10;
-  __shared__ double red[2][NBLK * 4][64];
+  // per wave two tiles of 16 rows in MFMA operand order: [slot][piece 2g+h][lane] x 16 bytes (64 KB per workgroup;
+  // the first 40 KB are the scratch of the final reduction)
+  __shared__ __attribute__((aligned(16))) v2d sTile[kBlock / 64][2][8][64];
   __shared__ uint32_t sDefRow[kBlock / 64][kDefCap];
   __shared__ double sDefPsi[kBlock / 64][kDefCap];
   __shared__ double sDefN[kBlock / 64][kDefCap];
@@ -121,6 +123,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
   const int64_t r1 = (r0 + per_wave) < N ? (r0 + per_wave) : N;
   int nDef = 0;                                          // wave-uniform
   unsigned long long ndeferred = 0;
+
+  // tile at `base` -> slot s: eight LDS-DMA pieces (rows past r1 read the range's last row; their weight is 0)
+  auto dma_tile = [&](int64_t base, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t row = base + 4 * g + k;
+      const double* p = tX + (size_t)(row < r1 ? row : r1 - 1) * 64 + 2 * c;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) __builtin_amdgcn_global_load_lds(p + 32 * h, &sTile[wave][s][2 * g + h][0], 16, 0, 0);
+    }
+  };
 
   // draw the first min(nDef, 16) rows of the list with the full sampler, add them, drop them from the list
   auto handle = [&]() __attribute__((always_inline)) {
@@ -164,19 +177,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
     nDef = rest;
   };
 
-  unsigned long long tWait = 0, tValu = 0, tMfma = 0;
-  auto step = [&](const Tile& T, int64_t base) __attribute__((always_inline)) {
-    unsigned long long s0 = 0, s1 = 0, s2 = 0;
-    if (VAR == 3) {
-      s0 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_waitcnt(0x0F70 | 9 | (0 << 14));   // vmcnt(9): everything but the prefetch just issued
-      s1 = __builtin_amdgcn_s_memtime();
-    }
-    // psi of the tile's 16 rows (the arithmetic of k_psi_omega_nb: four products in column order, 16-lane butterfly)
+  // psi of the 16 rows of the tile in slot s (the arithmetic of k_psi_omega_nb: four products in column order,
+  // 16-lane butterfly); lane (k, c) keeps row 4 (c >> 2) + k
+  auto psi_of = [&](int s) __attribute__((always_inline)) -> double {
     double psi = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const double xg[4] = {T.v[g][0].x, T.v[g][0].y, T.v[g][1].x, T.v[g][1].y};
+      const v2d v0 = sTile[wave][s][2 * g][lane], v1 = sTile[wave][s][2 * g + 1][lane];
+      const double xg[4] = {v0.x, v0.y, v1.x, v1.y};
       double part = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) part += xg[q] * bq[q];
@@ -186,22 +194,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
       part += __shfl_xor(part, 8);
       psi = (gq == g) ? part : psi;
     }
-    const int64_t row = base + 4 * gq + k;
-    const bool inrange = row < r1;
+    return psi;
+  };
+
+  // the four attempts of every row of a tile (straight-line): verdict 0 / 1 / 2 and the proposal X
+  auto attempts = [&](double psi, int64_t row, double& X) __attribute__((always_inline)) -> int {
     const double Z = fabs(psi) * 0.5;                                  // PolyaGamma.cpp:154
-    const bool fast = inrange && (kSmTRecip > Z) && T.nn == 1.0;       // :87; n = 1: one PG(1, psi) draw
-    // attempt a of the row, state known: a = 0 fresh, a > 0 a retry inside the left piece
-    const double Zs = fast ? Z : 0.0;                                  // the others run the body on z = 0 and are ignored
-    const double fz = kSmPiSq8 + 0.5 * Zs * Zs;                        // :157
-    const double mass = pg1_mass_small(Zs, fz);
+    const double fz = kSmPiSq8 + 0.5 * Z * Z;                          // :157
+    const double mass = pg1_mass_small(Z, fz);                         // rows outside the class are masked by the caller
     const uint64_t idx = idx0 + (uint64_t)row;
     const U4 o = philox4x32_10((uint32_t)idx, ctr1_of(idx, DOM_OMEGA), epoch, (uint32_t)a, k0, k1);
-    double X;
-    int verdict;
-    if (VAR == 1) { X = 1.0 + Zs; verdict = 1; }
-    else verdict = pg1_attempt_small_known<true>(a == 0, Zs, fz, mass, u52(o.x, o.y), u52(o.z, o.w), X);
-    // the row's first attempt (in block order) that does not end in a retry decides: accepted -> the draw;
-    // series test open, or none of the four -> deferred
+    return pg1_attempt_small_known(a == 0, Z, fz, mass, u52(o.x, o.y), u52(o.z, o.w), X);
+  };
+
+  // the row's first attempt (in block order) that does not end in a retry decides: accepted -> the draw;
+  // series test open, or none of the four, or not a fast row -> deferred.  Returns omega (0 if deferred).
+  auto settle = [&](double psi, double nn, int64_t row, int verdict, double X) __attribute__((always_inline)) -> double {
+    const bool inrange = row < r1;
+    const bool fast = inrange && (kSmTRecip > fabs(psi) * 0.5) && nn == 1.0;   // :87; n = 1: one PG(1, psi) draw
     const uint64_t bAcc = __ballot(fast && verdict == 1), bStop = __ballot(fast && verdict != 0);
     const int sh = lane & ~3;
     const uint32_t nAcc = (uint32_t)(bAcc >> sh) & 15u, nStop = (uint32_t)(bStop >> sh) & 15u;
@@ -217,45 +227,102 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
       const int slot = nDef + __popcll(dm & lt_mask);
       sDefRow[wave][slot] = (uint32_t)(row - r0);
       sDefPsi[wave][slot] = psi;
-      sDefN[wave][slot] = T.nn;
+      sDefN[wave][slot] = nn;
     }
     nDef += __popcll(dm);
     ndeferred += (unsigned long long)__popcll(dm);
-    if (VAR == 3) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      s2 = __builtin_amdgcn_s_memtime();
-    }
-    // X' Omega X of the tile
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const double x[4] = {T.v[g][0].x, T.v[g][0].y, T.v[g][1].x, T.v[g][1].y};
-      const double wg = __shfl(om, (lane & 48) | (4 * g));
-      if (VAR == 2) { acc[g][0] += wg * x[0]; } else
-      mfma_group(acc, x, wg);
-    }
-    if (VAR == 3) {
-      const unsigned long long s3 = __builtin_amdgcn_s_memtime();
-      tWait += s1 - s0;
-      tValu += s2 - s1;
-      tMfma += s3 - s2;
-    }
-    if (nDef >= 16) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      handle();
-    }
+    return om;
   };
 
-  const unsigned long long k0t = VAR == 3 ? __builtin_amdgcn_s_memtime() : 0, k0r = VAR == 3 ? __builtin_amdgcn_s_memrealtime() : 0;
   if (r0 < r1) {
-    Tile A, B;
-    tile_load(A, tX, nvec, r0, r1, k, c);
-    for (int64_t base = r0; base < r1; base += 32) {
-      if (base + 16 < r1) tile_load(B, tX, nvec, base + 16, r1, k, c);
-      step(A, base);
-      if (base + 16 >= r1) break;
-      if (base + 32 < r1) tile_load(A, tX, nvec, base + 32, r1, k, c);
-      step(B, base + 16);
+    const int64_t ntiles = (r1 - r0 + 15) / 16;
+    const int64_t myrow0 = r0 + 4 * gq + k;               // this lane's row of tile 0
+    // prologue: tiles 0 and 1 on their way, the draw of tile 0
+    dma_tile(r0, 0);
+    if (ntiles > 1) dma_tile(r0 + 16, 1);
+    double nn = nvec[myrow0 < r1 ? myrow0 : r1 - 1];
+    if (ntiles > 1) BL_WAIT_VM(9); else BL_WAIT_VM(1);
+    asm volatile("" ::: "memory");
+    double om;
+    {
+      const double psi = psi_of(0);
+      double X;
+      const int verdict = attempts(psi, myrow0, X);
+      om = settle(psi, nn, myrow0, verdict, X);
+    }
+    for (int64_t t = 0; t + 1 < ntiles; ++t) {
+      const int s = (int)(t & 1);
+      // tile t: slot -> registers (its DMA was waited for before its psi)
+      v2d xt[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xt[i] = sTile[wave][s][i][lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is free once the reads have returned
+      const int64_t row1 = myrow0 + 16 * (t + 1);
+      const double nn1 = nvec[row1 < r1 ? row1 : r1 - 1];
+      if (t + 2 < ntiles) {
+        dma_tile(r0 + 16 * (t + 2), s);
+        BL_WAIT_VM(9);                                     // all but nn1 and the eight pieces just issued: tile t+1 has landed
+      } else {
+        BL_WAIT_VM(1);
+      }
+      asm volatile("" ::: "memory");
+      const double psi1 = psi_of(s ^ 1);
+      // One basic block: the attempt of tile t+1 in stages, three or four of tile t's 40 MFMAs after each stage
+      // (the fences keep the scheduler from regrouping them).
+      double am[4][4], xm[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double wg = __shfl(om, (lane & 48) | (4 * g));
+        xm[g][0] = xt[2 * g].x, xm[g][1] = xt[2 * g].y, xm[g][2] = xt[2 * g + 1].x, xm[g][3] = xt[2 * g + 1].y;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) am[g][q] = wg * xm[g][q];
+      }
+      BL_MFMAS(0, 3);
+      const double Z = fabs(psi1) * 0.5;                               // PolyaGamma.cpp:154
+      const double fz = kSmPiSq8 + 0.5 * Z * Z;                        // :157
+      const uint64_t idx = idx0 + (uint64_t)row1;
+      PhiloxState ph{U4{(uint32_t)idx, ctr1_of(idx, DOM_OMEGA), epoch, (uint32_t)a}, k0, k1};
+      philox_rounds<2>(ph);
+      BL_MFMAS(3, 6);
+      philox_rounds<3>(ph);
+      BL_MFMAS(6, 9);
+      philox_rounds<3>(ph);
+      BL_MFMAS(9, 12);
+      philox_rounds<2>(ph);
+      const double u1 = u52(ph.c.x, ph.c.y), u2 = u52(ph.c.z, ph.c.w);
+      BL_MFMAS(12, 15);
+      const double mass = pg1_mass_small(Z, fz);            // rows outside the class are masked in settle()
+      BL_MFMAS(15, 19);
+      Pg1Staged st;
+      pg1_stage_w(st, a == 0, mass, u1);
+      BL_MFMAS(19, 22);
+      pg1_stage_log(st);
+      BL_MFMAS(22, 26);
+      pg1_stage_x(st, Z, fz);
+      BL_MFMAS(26, 29);
+      pg1_stage_A(st);
+      BL_MFMAS(29, 33);
+      pg1_stage_r3(st);
+      BL_MFMAS(33, 37);
+      const int verdict1 = pg1_stage_verdict(st, u2);
+      const double X1 = st.X;
+      BL_MFMAS(37, 40);
+      om = settle(psi1, nn1, row1, verdict1, X1);
+      if (nDef >= 16) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        handle();
+      }
+    }
+    {   // the last tile's MFMAs
+      const int s = (int)((ntiles - 1) & 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const v2d v0 = sTile[wave][s][2 * g][lane], v1 = sTile[wave][s][2 * g + 1][lane];
+        const double x[4] = {v0.x, v0.y, v1.x, v1.y};
+        const double wg = __shfl(om, (lane & 48) | (4 * g));
+        mfma_group(acc, x, wg);
+      }
     }
     if (nDef > 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -264,16 +331,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
     }
   }
   if (stats && lane == 0 && ndeferred) atomicAdd(stats, ndeferred);
-  if (VAR == 3 && stats && lane == 0) {
-    atomicAdd(stats + 2, tWait);
-    atomicAdd(stats + 3, tValu);
-    atomicAdd(stats + 4, tMfma);
-    atomicAdd(stats + 5, (unsigned long long)(__builtin_amdgcn_s_memtime() - k0t));
-    atomicAdd(stats + 6, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - k0r));
-    atomicAdd(stats + 7, 1ull);
-  }
 
   // fixed-order in-block reduction: (w0 + w2) + (w1 + w3)
+  __syncthreads();                                         // every wave is done with its slots
+  double (*red)[NBLK * 4][64] = reinterpret_cast<double (*)[NBLK * 4][64]>(&sTile[0][0][0][0]);
   if (wave >= 2) {
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
@@ -312,12 +373,7 @@ void launch_sweep_once64(int nblocks, const double* tX, const double* n, const d
                          double* partial, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s)
 {
-  static const int var = getenv("BL_SWEEP1_VARIANT") ? atoi(getenv("BL_SWEEP1_VARIANT")) : 0;
-  if (var == 1) hipLaunchKernelGGL(k_sweep_once64<1>, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, partial, status, stats);
-  else if (var == 3) hipLaunchKernelGGL(k_sweep_once64<3>, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, partial, status, stats);
-  else if (var == 2) hipLaunchKernelGGL(k_sweep_once64<2>, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, partial, status, stats);
-  else
-  hipLaunchKernelGGL(k_sweep_once64<0>, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, partial,
+  hipLaunchKernelGGL(k_sweep_once64, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, partial,
                      status, stats);
 }
 
