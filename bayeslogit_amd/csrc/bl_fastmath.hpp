@@ -68,8 +68,8 @@ BL_HD double bl_log(double x)
   const double s = bl_div(f, 2.0 + f);
   const double z = s * s;
   const double w = z * z;
-  const double t1 = w * fma_vvv(w, fma_vvv(w, Lg6, Lg4), Lg2);
-  const double t2 = z * fma_vvv(w, fma_vvv(w, fma_vvv(w, Lg7, Lg5), Lg3), Lg1);
+  const double t1 = w * fma_vvs(w, fma_vvs(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma_vvs(w, fma_vvs(w, fma_vvs(w, Lg7, Lg5), Lg3), Lg1);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
   const double dk = (double)k;
@@ -89,16 +89,16 @@ BL_HD double bl_exp_core(double x)
   const int k = (int)(uint32_t)sb;
   const double r = (x - kd * ln2_hi) - kd * ln2_lo;
   // exp(r), |r| <= 0.3466: Taylor to r^13 (truncation 4e-18)
-  double p = fma_vvv(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
-  p = fma_vvv(p, r, 1.0 / 39916800.0);
-  p = fma_vvv(p, r, 1.0 / 3628800.0);
-  p = fma_vvv(p, r, 1.0 / 362880.0);
-  p = fma_vvv(p, r, 1.0 / 40320.0);
-  p = fma_vvv(p, r, 1.0 / 5040.0);
-  p = fma_vvv(p, r, 1.0 / 720.0);
-  p = fma_vvv(p, r, 1.0 / 120.0);
-  p = fma_vvv(p, r, 1.0 / 24.0);
-  p = fma_vvv(p, r, 1.0 / 6.0);
+  double p = fma_vvs(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+  p = fma_vvs(p, r, 1.0 / 39916800.0);
+  p = fma_vvs(p, r, 1.0 / 3628800.0);
+  p = fma_vvs(p, r, 1.0 / 362880.0);
+  p = fma_vvs(p, r, 1.0 / 40320.0);
+  p = fma_vvs(p, r, 1.0 / 5040.0);
+  p = fma_vvs(p, r, 1.0 / 720.0);
+  p = fma_vvs(p, r, 1.0 / 120.0);
+  p = fma_vvs(p, r, 1.0 / 24.0);
+  p = fma_vvs(p, r, 1.0 / 6.0);
   p = p * r + 0.5;
   p = p * r + 1.0;
   p = p * r + 1.0;

@@ -39,10 +39,12 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
                   double* xoc = nullptr);
 
 // The same sweep with X read once (kernels_sweep1.hip): P = 64, W_DRAW, no offset.  launch_sweep takes this path
-// when sweep_single_pass() is on (default; bl_set_sweep_mode) and the call is eligible; same omega bit for bit,
-// PPpart in another (fixed) summation order.  stats (or nullptr): += the number of rows that left the fast path.
+// when sweep_single_pass() is on (default; bl_set_sweep_mode) and the call is eligible; same omega (to the last bits),
+// PPpart in another (fixed) summation order.  ws: sweep_once64_ws_doubles(nblocks, N) doubles (make_plan sizes the
+// plan's workspace for it); stats (or nullptr): += the number of rows that left the fast path.
+size_t sweep_once64_ws_doubles(int nblocks, int64_t N);
 void launch_sweep_once64(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
-                         double* partial, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
+                         double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s);
 
 // out[j] = sum_i wgt_i x_ij, with wgt_i = n_i (y_i - 1/2) (kappa, Logit.hpp:174-183)

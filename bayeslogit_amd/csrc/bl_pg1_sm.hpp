@@ -93,7 +93,7 @@ BL_HD double pg1_mass_small(double Z, double fz)
   const double s = (2.0 * kSmT * kSmT) * Z * Z - 1.0;
   double g = kMassPoly[kMassPolyN - 1];
 #pragma unroll
-  for (int k = kMassPolyN - 2; k >= 0; --k) g = fma_vvv(g, s, kMassPoly[k]);
+  for (int k = kMassPolyN - 2; k >= 0; --k) g = fma_vvs(g, s, kMassPoly[k]);
   const double qdivp = 4.0 / kSmPi * fz * g;
   return bl_div(1.0, 1.0 + qdivp);
 }

@@ -36,9 +36,18 @@ __device__ __forceinline__ double fma_vvv(double a, double b, double c)
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// The same with the addend in a scalar register pair: for a compile-time constant c the two halves are then set by
+// scalar moves, which issue beside other waves' vector instructions, instead of two v_mov_b32 per step.
+__device__ __forceinline__ double fma_vvs(double a, double b, double c)
+{
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
 }  // namespace bl
 #else
 namespace bl {
 inline double fma_vvv(double a, double b, double c) { return fma(a, b, c); }
+inline double fma_vvs(double a, double b, double c) { return fma(a, b, c); }
 }  // namespace bl
 #endif

@@ -161,9 +161,6 @@ int bl_diag_sweep_deferred(uint64_t* rows)
     return BL_ERR_HIP;
   }
   if (rows) *rows = v[0];
-  if (v[7])      // development build of the kernel (BL_SWEEP1_VARIANT=3): per-wave phase stamps
-    fprintf(stderr, "sweep1 stamps per wave (shader cycles): load wait %.0f, psi+attempt %.0f, mfma issue %.0f, kernel %.0f; clock %.0f MHz\n",
-            (double)v[2] / v[7], (double)v[3] / v[7], (double)v[4] / v[7], (double)v[5] / v[7], 100.0 * v[5] / (double)v[6]);
   return BL_OK;
 }
 void bl_set_device_R(int* device, int* rc)

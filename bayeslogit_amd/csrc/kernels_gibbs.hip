@@ -906,6 +906,10 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     p.nblocks = (int)nb;
     plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2 + p.nb) * 4 * 64;   // + the X' Omega c blocks of mlogit
+    if (P == 64) {                                                                     // the single-pass sweep's workspace
+      const size_t once = sweep_once64_ws_doubles(p.nblocks, N);
+      if (once > p.partial_doubles) p.partial_doubles = once;
+    }
   } else {
     p.fused = 0;
     const int T = (P + 63) / 64;
@@ -935,10 +939,8 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
   if (plan.fused == 1 && plan.P == 64 && mode == W_DRAW && !off && parts == 3 && !xoc && N > 0 &&
       blh::sweep_single_pass()) {
     // X read once (kernels_sweep1.hip); omega is stored only if the caller wants it
-    constexpr int E = 10 * 4 * 64;
-    launch_sweep_once64(plan.nblocks, tX, n, beta, w_store, N, partial, seed, epoch, idx0, status, blh::sweep_stats(), s);
-    hipLaunchKernelGGL((k_reduce_fused<4, false>), dim3((E + 63) / 64), dim3(1024), 0, s, partial, plan.nblocks, PPpart,
-                       plan.P, nullptr);
+    launch_sweep_once64(plan.nblocks, tX, n, beta, w_store, N, partial, PPpart, seed, epoch, idx0, status,
+                        blh::sweep_stats(), s);
     return;
   }
   if (plan.fused) {

@@ -112,6 +112,18 @@ def fill_logit_y(y, X, beta, seed, epoch=0, idx0=0):
     return y
 
 
+def set_sweep_mode(single_pass=True):
+    """P = 64 Gibbs sweeps read X once (default) or in two streaming passes (bl_set_sweep_mode)."""
+    _lib.lib().bl_set_sweep_mode(1 if single_pass else 0)
+
+
+def sweep_deferred_rows():
+    """Rows the single-pass sweep handed to the full sampler since the last call (synchronises the device)."""
+    v = C.c_uint64(0)
+    _lib.check(_lib.lib().bl_diag_sweep_deferred(C.byref(v)), "bl_diag_sweep_deferred")
+    return int(v.value)
+
+
 class GibbsShard:
     """This rank's rows of the logistic Gibbs problem (bl_gibbs handle).
 

@@ -146,6 +146,52 @@ def test_sweep_with_many_large_psi_rows(gpu, oracle, scale, P):
     g.close()
 
 
+@pytest.mark.parametrize("N,nmax,scale", [(1, 1, 1.0), (15, 1, 1.0), (16, 3, 1.0), (17, 1, 1.0), (4097, 1, 1.0),
+                                          (100003, 1, 1.0), (100003, 3, 1.0), (50000, 1, 8.0), (20011, 1, 0.0)])
+def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale):
+    """P = 64 sweeps run on kernels_sweep1.hip (X read once; rows outside the fast path -- attempts 0..3 all retries,
+    first series test open, |psi|/2 >= 1/t, n != 1 -- drawn by a second kernel) unless bl_set_sweep_mode(0) selects the two
+    streaming passes.  Same omega (the deferred rows' sampler is another instantiation: 1e-13), same X'Omega X up to
+    summation order, both next to the oracle; omega not requested gives the same X'Omega X bit for bit."""
+    from bayeslogit_amd import device as D
+    P = 64
+    X, y, n = synth(N, P, 3 * N + nmax, nmax=nmax)
+    beta0 = np.linspace(-1.0, 1.0, P) * scale
+    out = {}
+    try:
+        for mode in (0, 1):
+            D.set_sweep_mode(bool(mode))
+            g = shard_of(X, y, n, gpu, seed=31, idx0=123456789012)
+            g.set_beta(beta0)
+            w = torch.full((N,), -1.0, dtype=torch.float64, device=gpu)
+            D.sweep_deferred_rows()
+            g.sweep_local(3, w)
+            D.sync_status()
+            nd = D.sweep_deferred_rows()
+            PP = g.pp().cpu().numpy().reshape(P, P).copy()
+            g.sweep_local(3, None)
+            D.sync_status()
+            assert np.array_equal(PP, g.pp().cpu().numpy().reshape(P, P))
+            out[mode] = (w.cpu().numpy(), PP, nd)
+            g.close()
+    finally:
+        D.set_sweep_mode(True)
+    (w0, PP0, nd0), (w1, PP1, nd1) = out[0], out[1]
+    assert nd0 == 0
+    assert np.allclose(w1, w0, rtol=1e-13, atol=0)
+    assert np.array_equal(PP1, PP1.T)
+    assert np.abs(PP1 - PP0).max() <= 1e-13 * np.abs(PP0).max()
+    PPo, wo = oracle.sweep_partial(X, n, beta0, 31, 3, 123456789012)
+    rel = np.abs(w1 - wo) / np.abs(wo)
+    assert (rel > 1e-10).sum() <= 1e-5 * N + 1, rel.max()
+    if (rel > 1e-10).sum() == 0:
+        assert np.abs(PP1 - PPo).max() <= 1e-12 * np.abs(PPo).max()
+    if nmax == 1 and scale <= 1.0 and N > 1000:
+        assert 0 < nd1 < 0.05 * N, nd1          # the fast path takes nearly every row of such a problem
+    if nmax == 3:
+        assert nd1 >= (n != 1).sum()
+
+
 def test_kernel_paths_agree_on_padded_data(gpu):
     """The same data with zero columns appended takes different kernels: P = 64 the register-tile MFMA
     kernels on 16-byte loads, P = 63+1 zero... P = 65 the LDS-tile MFMA kernel with masked 8-byte loads
