@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbayeslogit_hip.so")
+LIB_PATH = os.environ.get("BAYESLOGIT_LIB", os.path.join(_HERE, "libbayeslogit_hip.so"))   # override: A/B builds
 _LIB = None
 
 c_d = C.c_double
@@ -51,6 +51,7 @@ SIGNATURES = {
     "bl_rpg_sp_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_u64, c_u32, c_u64, c_vp]),
     "bl_rpg_gamma_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),
     "bl_diag_mfma_f64_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
+    "bl_diag_mfma_f64_small_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
     "bl_fill_unif_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),
     "bl_fill_norm_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),
     "bl_fill_shape_dev": (C.c_int, [c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),

@@ -47,6 +47,12 @@ void launch_sweep_once64(int nblocks, const double* tX, const double* n, const d
                          double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s);
 
+// X' Omega X for P = 128 (nc = 8 chunks of 16 columns) or 256 (nc = 16) on v_mfma_f64_4x4x4_4b_f64 (kernels_xwx4.hip),
+// one workgroup of nc/2 waves per block; partial: xwx_q4_big_ws_doubles(nblocks, nc) doubles.
+size_t xwx_q4_big_ws_doubles(int nblocks, int nc);
+void launch_xwx_q4_big(int nblocks, int nc, const double* tX, const double* w, int64_t N, double* partial, double* PP,
+                       hipStream_t s);
+
 // out[j] = sum_i wgt_i x_ij, with wgt_i = n_i (y_i - 1/2) (kappa, Logit.hpp:174-183)
 // when w == nullptr, else wgt_i = w_i * c_i (c may be nullptr => 1).
 // ws: workspace of colsum_ws_doubles(N, P) doubles.

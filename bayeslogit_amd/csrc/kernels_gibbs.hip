@@ -15,6 +15,7 @@
 //   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
 #include "bl_gibbs_kernels.hpp"
+#include <stdlib.h>
 #include "bl_host.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_queue.hpp"
@@ -839,6 +840,11 @@ void launch_nb_big_x(const blk::SweepPlan& plan, const double* tX, const double*
   constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
   if (parts & 1) launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
   if (!(parts & 2)) return;
+  static const bool big_mfma = getenv("BL_XWX_BIG_MFMA") != nullptr;   // development aid: the 16x16x4 kernel below
+  if (!big_mfma && EXACT && N > 0) {      // P = 128 / 256: the small matrix instruction (kernels_xwx4.hip)
+    blk::launch_xwx_q4_big(plan.nblocks, NB, tX, w, N, partial, PP, s);
+    return;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)k_xwx_mfma_big<NB, NW, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -896,6 +902,7 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     p.nblocks = (int)nb;
     plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 256;
+    if (xwx_q4_big_ws_doubles(p.nblocks, p.nb) > p.partial_doubles) p.partial_doubles = xwx_q4_big_ws_doubles(p.nblocks, p.nb);
   } else if (P >= 1 && P <= 64) {
     p.fused = 1;
     p.nb = (P + 15) / 16;                        // columns padded (as zeros, in registers) to 16 nb

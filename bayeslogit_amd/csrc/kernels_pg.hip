@@ -320,6 +320,23 @@ __global__ __launch_bounds__(256) void k_diag_mfma_f64(double* __restrict__ out,
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
+// the same loop on v_mfma_f64_4x4x4_4b_f64 (512 flops), the instruction the P >= 64 X' Omega X kernels use
+__global__ __launch_bounds__(256) void k_diag_mfma_f64_small(double* __restrict__ out, int iters, double a0, double b0)
+{
+  double acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+  const double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double sum = 0.0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sum += acc[i];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
 }  // namespace
 
 // =============================================================== Part 2 (device)
@@ -427,6 +444,28 @@ int bl_diag_mfma_f64_dev(double* work, int64_t work_doubles, int waves_per_simd,
   hipLaunchKernelGGL(k_diag_mfma_f64, dim3(grid), dim3(256), 0, (hipStream_t)stream, work, iters, 1.0, 1.0);
   BL_HIP_TRY(hipGetLastError());
   *flops = (double)grid * 4.0 * (double)iters * 10.0 * 2048.0;   // 16*16*4 multiply-adds per instruction
+  return BL_OK;
+}
+
+int bl_diag_mfma_f64_small_dev(double* work, int64_t work_doubles, int waves_per_simd, int iters, double* flops,
+                               void* stream)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  if (!work || !flops || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1) {
+    blh::set_error("bl_diag_mfma_f64_small_dev: bad argument");
+    return BL_ERR_ARG;
+  }
+  int dev = 0, cus = 0;
+  BL_HIP_TRY(hipGetDevice(&dev));
+  BL_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = cus * waves_per_simd;
+  if (work_doubles < (int64_t)grid * 256) {
+    blh::set_error("bl_diag_mfma_f64_small_dev: work buffer too small");
+    return BL_ERR_ARG;
+  }
+  hipLaunchKernelGGL(k_diag_mfma_f64_small, dim3(grid), dim3(256), 0, (hipStream_t)stream, work, iters, 1.0, 1.0);
+  BL_HIP_TRY(hipGetLastError());
+  *flops = (double)grid * 4.0 * (double)iters * 10.0 * 512.0;    // four blocks of 4*4*4 multiply-adds per instruction
   return BL_OK;
 }
 

@@ -69,16 +69,17 @@ def rpg_sp(h, z, seed=0, epoch=0, idx0=0, out=None, iters=None):
     return _rpg_h(_lib.lib().bl_rpg_sp_dev, "bl_rpg_sp_dev", h, z, seed, epoch, idx0, out, _ptr(iters))
 
 
-def mfma_f64_sustained_tflops(waves_per_simd=2, iters=4000):
-    """Measured rate of a register-only v_mfma_f64_16x16x4_f64 loop (bl_diag_mfma_f64_dev), TFLOP/s."""
+def mfma_f64_sustained_tflops(waves_per_simd=2, iters=4000, small=False):
+    """Measured rate of a register-only loop of v_mfma_f64_16x16x4_f64 (bl_diag_mfma_f64_dev) or, small=True, of
+    v_mfma_f64_4x4x4_4b_f64 (bl_diag_mfma_f64_small_dev), TFLOP/s."""
     work = torch.empty(1024 * 8 * 256, dtype=torch.float64, device="cuda")
     fl = C.c_double(0.0)
     best = 0.0
+    fn = _lib.lib().bl_diag_mfma_f64_small_dev if small else _lib.lib().bl_diag_mfma_f64_dev
     for rep in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(_lib.lib().bl_diag_mfma_f64_dev(_ptr(work), work.numel(), waves_per_simd, iters, C.byref(fl),
-                                                   _stream()), "bl_diag_mfma_f64_dev")
+        _lib.check(fn(_ptr(work), work.numel(), waves_per_simd, iters, C.byref(fl), _stream()), "bl_diag_mfma_f64_dev")
         e1.record()
         e1.synchronize()
         if rep:

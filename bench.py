@@ -327,8 +327,24 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
                      "max_abs_z": float(np.max(np.abs(mean - bt_h) / np.maximum(sd, 1e-300)))}
     sk = res["constrained"]["sweep_kernel_ms"]
     gb = 8.0 * nl * P / (sk * 1e-3) / 1e9
-    if P <= 64:
-        nbk = P // 16
+    if P == 64:
+        # kernels_sweep1.hip: psi, the draws and X' Omega X in ONE pass over X (rows that leave the fast path: second kernel)
+        roof = {"kernel": "k_sweep_once64 + k_sweep_deferred64 + k_reduce_q4 (one sweep: ONE pass over X)", "bound": "hbm",
+                "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": 8 * nl * P,
+                "note": "algorithmic bytes = X once (SURVEY 8d), which is what the sweep reads; what bounds it is the "
+                        "instruction total (545 vector + 144 small matrix instructions per 16 rows; fp64 vector and "
+                        "matrix instructions do not overlap on gfx950), DESIGN.md 4.3",
+                }
+        D.sweep_deferred_rows()                    # (reset) rows of ONE sweep at the chain's current beta that left the fast path
+        shard.sweep_local(1 << 20, None)
+        roof["deferred_rows_per_sweep"] = D.sweep_deferred_rows()
+        t1, src = pmc_traffic("k_sweep_once64")
+        t2, _ = pmc_traffic("k_sweep_deferred64")
+        roof["traffic"] = (t1 + (t2 or 0.0)) if (t1 and N == 10_000_000 and world == 1) else None
+        roof["traffic_source"] = src
+    elif P < 64:
+        nbk = (P + 15) // 16
         kernels = f"k_psi_omega_nb<{nbk},0> + k_xwx_mfma<{nbk}> + k_reduce_fused<{nbk}>"
         roof = {"kernel": kernels + " (one sweep: two passes over X)", "bound": "hbm", "achieved": gb,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
@@ -344,21 +360,26 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         tri = nbk * (nbk + 1) // 2
         flops = 2.0 * nl * tri * 256                       # upper-triangle 16x16 blocks of the rank-N update
         tf = flops / (sk * 1e-3) / 1e12
-        roof = {"kernel": f"k_psi_omega_nb<{nbk},0> + k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>", "bound": "mfma",
+        xk = f"k_xwx_q4_big<{nbk}> + k_reduce_q4_big<{nbk}>" if P in (128, 256) else f"k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>"
+        roof = {"kernel": f"k_psi_omega_nb<{nbk},0> + " + xk, "bound": "mfma",
                 "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": None, "algorithmic_flops_per_launch": flops,
                 "note": "whole sweep time (both passes) against the fp64 MFMA peak; X' Omega X alone is "
-                        "k_xwx_mfma_big in profiles/"}
+                        "k_xwx_q4_big in profiles/"}
     roof["kernel_ms"] = sk
     # the fp64 matrix pipe as measured on this GPU (register-only MFMA loop, 2 waves/SIMD): the X'Omega X pass
     # cannot take less than its flops at that rate
     tri_b = (P // 16) * (P // 16 + 1) // 2 if P % 16 == 0 else ((P + 15) // 16) * ((P + 15) // 16 + 1) // 2
     xwx_flops = 2.0 * nl * tri_b * 256
     sustained = D.mfma_f64_sustained_tflops(2)
+    sustained_small = D.mfma_f64_sustained_tflops(2, small=True)
     roof["mfma_f64"] = {"sustained_tflops_measured": sustained, "nominal_tflops": FP64_MFMA_PEAK_TFLOPS,
+                        "small_instruction_tflops_measured": sustained_small,
                         "xwx_flops_per_sweep": xwx_flops, "xwx_ms_at_sustained": xwx_flops / (sustained * 1e12) * 1e3,
-                        "note": "pass 2 (X' Omega X on v_mfma_f64_16x16x4_f64) is bounded by this, not by HBM; its "
-                                "measured average is in profiles/ (kernel stats)"}
+                        "xwx_ms_at_small_instruction_rate": xwx_flops / (sustained_small * 1e12) * 1e3,
+                        "note": "register-only loops, 2 waves/SIMD: v_mfma_f64_16x16x4_f64 (sustained_tflops_measured) and "
+                                "v_mfma_f64_4x4x4_4b_f64 (small_instruction_tflops_measured), which X' Omega X runs on for "
+                                "P = 64, 128, 256 (P < 64 and padded P: the big instruction)"}
     if roof["bound"] == "mfma":
         roof["frac_of_sustained"] = roof["achieved"] / sustained
     outg = {

@@ -130,6 +130,9 @@ int bl_fill_shape_dev(double *out, int64_t num, int kmax,
  * performs (the caller times it with events on `stream`).  work: >= CUs * waves_per_simd * 256 doubles. */
 int bl_diag_mfma_f64_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
                          void *stream);
+/* the same loop on v_mfma_f64_4x4x4_4b_f64 (512 flops), the instruction the X' Omega X kernels for P >= 64 are built on */
+int bl_diag_mfma_f64_small_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
+                               void *stream);
 /* The Gibbs sweep over a rank's rows (Logit.hpp:283-301,431: psi = X beta, omega ~ PG(n, psi), X' Omega X) reads X
  * once when P = 64 (single_pass = 1, the default; env BL_SWEEP_SINGLE_PASS) or in two streaming passes
  * (single_pass = 0; every other P).  Same omega bit for bit; X' Omega X in another, equally fixed, summation order.

@@ -3,6 +3,7 @@
 //   (a) v_mfma_f64_16x16x4_f64 (2048 flops) and v_mfma_f64_4x4x4_4b_f64 (512 flops), NACC independent accumulators,
 //       W waves per SIMD: shader cycles per instruction per SIMD (s_memtime) and the clock the chip holds
 //       (s_memtime / s_memrealtime);
+//   (c) the 4x4x4 loop with its B operand read from LDS by one ds_read_b64 per matrix instruction (the P = 256 kernel's mix);
 //   (b) the 16x16x4 loop with F independent v_fma_f64 per matrix instruction in the same wave: if the vector FMAs ran
 //       in the matrix instruction's shadow the cycles per iteration would stay put; they add up instead.
 // Build here (hipcc cross-compiles), run on the GPU box:  scripts/experiments/mfma_f64_shapes
@@ -11,9 +12,12 @@
 #include <cstdlib>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int SHAPE, int NACC, int F>
+template <int SHAPE, int NACC, int F, int L = 0>
 __global__ __launch_bounds__(256) void k(double* out, unsigned long long* clk, int iters, double a0)
 {
+  __shared__ double sb[4][64 * 17];
+  if (L) { for (int i = threadIdx.x; i < 4 * 64 * 17; i += 256) (&sb[0][0])[i] = 1.0 + i * 1e-9; __syncthreads(); }
+  const double* lp = &sb[threadIdx.x >> 6][threadIdx.x & 63];
   d4 acc16[SHAPE == 16 ? NACC : 1];
   double acc4[SHAPE == 4 ? NACC : 1];
   double f[F > 0 ? F : 1];
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void k(double* out, unsigned long long* clk, i
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       if (SHAPE == 16) acc16[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc16[i], 0, 0, 0);
-      if (SHAPE == 4) acc4[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc4[i], 0, 0, 0);
+      if (SHAPE == 4) acc4[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, L ? lp[64 * (i % 16)] : b, acc4[i], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < F; ++j) f[j] = __builtin_fma(f[j], b, a);
     }
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void k(double* out, unsigned long long* clk, i
   }
 }
 
-template <int SHAPE, int NACC, int F>
+template <int SHAPE, int NACC, int F, int L = 0>
 static void run(int wg_per_cu, int iters)
 {
   hipDeviceProp_t prop;
@@ -59,7 +63,7 @@ static void run(int wg_per_cu, int iters)
   unsigned long long *clk, *h = (unsigned long long*)malloc(sizeof(unsigned long long) * 2 * grid);
   hipMalloc(&out, (size_t)grid * 256 * sizeof(double));
   hipMalloc(&clk, sizeof(unsigned long long) * 2 * grid);
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<SHAPE, NACC, F>), dim3(grid), dim3(256), 0, 0, out, clk, iters, 1.0);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<SHAPE, NACC, F, L>), dim3(grid), dim3(256), 0, 0, out, clk, iters, 1.0);
   hipDeviceSynchronize();
   hipMemcpy(h, clk, sizeof(unsigned long long) * 2 * grid, hipMemcpyDeviceToHost);
   double cyc = 0, real = 0;
@@ -68,8 +72,8 @@ static void run(int wg_per_cu, int iters)
   const double per_iter_simd = cyc / ((double)iters * NACC) / wg_per_cu;   // per matrix instruction (and its F FMAs) per SIMD
   const double ghz = cyc / real * 0.1;
   const double flops = SHAPE == 16 ? 2048.0 : 512.0;
-  printf("shape %2dx%2dx4  acc %2d  fma/mfma %2d  waves/SIMD %d: %6.1f cycles per matrix instruction per SIMD, clock %.2f GHz, %.1f TFLOP/s matrix\n",
-         SHAPE, SHAPE, NACC, F, wg_per_cu, per_iter_simd, ghz,
+  printf("shape %2dx%2dx4  acc %2d  fma/mfma %2d  lds reads/mfma %d  waves/SIMD %d: %6.1f cycles per matrix instruction per SIMD, clock %.2f GHz, %.1f TFLOP/s matrix\n",
+         SHAPE, SHAPE, NACC, F, L, wg_per_cu, per_iter_simd, ghz,
          flops / per_iter_simd * ghz * 1e9 * prop.multiProcessorCount * 4 / 1e12);
   hipFree(out), hipFree(clk), free(h);
 }
@@ -90,5 +94,8 @@ int main()
   run<4, 16, 2>(2, it);
   run<4, 16, 4>(2, it);
   run<16, 0 + 1, 0>(1, it);
+  run<4, 16, 0, 1>(2, it);
+  run<4, 16, 0, 1>(4, it);
+  run<4, 32, 0, 1>(2, it);
   return 0;
 }
