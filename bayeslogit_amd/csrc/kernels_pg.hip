@@ -323,17 +323,17 @@ __global__ __launch_bounds__(256) void k_diag_mfma_f64(double* __restrict__ out,
 // the same loop on v_mfma_f64_4x4x4_4b_f64 (512 flops), the instruction the P >= 64 X' Omega X kernels use
 __global__ __launch_bounds__(256) void k_diag_mfma_f64_small(double* __restrict__ out, int iters, double a0, double b0)
 {
-  double acc[10];
+  double acc[32];             // (a result comes back later than ten issue slots: 32 independent chains)
 #pragma unroll
-  for (int i = 0; i < 10; ++i) acc[i] = 0.0;
+  for (int i = 0; i < 32; ++i) acc[i] = 0.0;
   const double a = a0 + threadIdx.x * 1e-9, b = b0;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
   }
   double sum = 0.0;
 #pragma unroll
-  for (int i = 0; i < 10; ++i) sum += acc[i];
+  for (int i = 0; i < 32; ++i) sum += acc[i];
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
 }
 
@@ -465,7 +465,7 @@ int bl_diag_mfma_f64_small_dev(double* work, int64_t work_doubles, int waves_per
   }
   hipLaunchKernelGGL(k_diag_mfma_f64_small, dim3(grid), dim3(256), 0, (hipStream_t)stream, work, iters, 1.0, 1.0);
   BL_HIP_TRY(hipGetLastError());
-  *flops = (double)grid * 4.0 * (double)iters * 10.0 * 512.0;    // four blocks of 4*4*4 multiply-adds per instruction
+  *flops = (double)grid * 4.0 * (double)iters * 32.0 * 512.0;    // four blocks of 4*4*4 multiply-adds per instruction
   return BL_OK;
 }
 

@@ -311,10 +311,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
 }
 
 // The rows k_sweep_once64 left: wave w of this grid (the same grid) takes the list wave w of that kernel wrote into
-// its own row range, 16 rows at a time: the full sampler for each (lane (k, 4g .. 4g+3) draws entry 4g + k), the rows of
-// X gathered into the wave's slot by LDS-DMA (piece p = slot bytes [1024 p, 1024 p + 1024) = rows 2p, 2p + 1; lane i
-// brings the 16 bytes stored at row 2p + (i >> 5), chunk (i >> 3) & 3, unit i & 7, i.e. columns of chunk
-// ((i >> 3) & 3) ^ (row & 1)), then the same 144 matrix instructions.  Its slabs follow the first kernel's.
+// its own row range, 64 rows at a time: one lane per row runs the full sampler (the kernel's time is the longest wave's
+// chain of draws, so they are taken 64 abreast), the weights go through LDS, and the rows of X are gathered 16 at a time
+// into one of the wave's two slots by LDS-DMA (piece p = slot bytes [1024 p, 1024 p + 1024) = rows 2p, 2p + 1; lane i brings
+// the 16 bytes stored at row 2p + (i >> 5), chunk (i >> 3) & 3, unit i & 7, i.e. columns of chunk ((i >> 3) & 3) ^ (row & 1))
+// while the previous 16 go through the same 144 matrix instructions.  Its slabs follow the first kernel's.
 __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __restrict__ tX,
                                                                 const double* __restrict__ nvec, double* __restrict__ w,
                                                                 int64_t N, uint64_t seed, uint32_t epoch, uint64_t idx0,
@@ -324,42 +325,58 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __
                                                                 const uint32_t* __restrict__ defCnt,
                                                                 unsigned long long* __restrict__ stats)
 {
-  __shared__ __attribute__((aligned(16))) char sTile[kBlock / 64][10240];
+  __shared__ __attribute__((aligned(16))) char sTile[kBlock / 64][2][8192];   // (the first 36 KB: scratch of the reduction)
+  __shared__ double sOm[kBlock / 64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = lane >> 4, c = lane & 15, a = c & 3, gq = c >> 2;
+  const int k = lane >> 4, gq = (lane >> 2) & 3;
   double acc[kNAcc];
 #pragma unroll
   for (int b = 0; b < kNAcc; ++b) acc[b] = 0.0;
   int oB[4][2];
   operand_offsets(oB, lane);
-  char* const slot = &sTile[wave][0];
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
   const int64_t per_wave = ((N + nwaves - 1) / nwaves + 15) / 16 * 16;
   const int64_t r0 = ((int64_t)blockIdx.x * (kBlock / 64) + wave) * per_wave;
   const int cnt = r0 < N ? (int)defCnt[blockIdx.x * (kBlock / 64) + wave] : 0;
-  for (int b0 = 0; b0 < cnt; b0 += 16) {
-    const int c16 = (cnt - b0) < 16 ? (cnt - b0) : 16;
+  // the 16 rows of the list from position b on -> slot s
+  auto gather = [&](int b, int s) __attribute__((always_inline)) {
+    const int c16 = (cnt - b) < 16 ? (cnt - b) : 16;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int row = 2 * p + (lane >> 5);
-      const int64_t grow = r0 + (int64_t)defRow[r0 + b0 + (row < c16 ? row : 0)];
+      const int64_t grow = r0 + (int64_t)defRow[r0 + b + (row < c16 ? row : 0)];
       const double* src = tX + (size_t)grow * 64 + 16 * (((lane >> 3) & 3) ^ (row & 1)) + 2 * (lane & 7);
-      __builtin_amdgcn_global_load_lds(src, slot + 1024 * p, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src, &sTile[wave][s][1024 * p], 16, 0, 0);
     }
-    const int e = 4 * gq + k;
-    const bool valid = e < c16;
-    const int64_t grow = r0 + (int64_t)defRow[r0 + b0 + (valid ? e : 0)];
+  };
+  for (int b0 = 0; b0 < cnt; b0 += 64) {
+    const int c64 = (cnt - b0) < 64 ? (cnt - b0) : 64;
+    gather(b0, 0);                                          // on its way while the draws run
     double om = 0.0;
-    if (valid)
-      om = draw_full((int)nvec[grow] /* (int) n(i), Logit.hpp:287 */, defPsi[r0 + b0 + e], seed, idx0 + (uint64_t)grow, epoch, status);
-    if (w && valid && a == 0) w[grow] = om;
-    BL_WAIT_VM(0);                                          // the eight pieces have landed
-    asm volatile("" ::: "memory");
-    mfma_tile(acc, slot, oB, om, lane);                     // weight 0 for the entries past c16
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot is read out before the next batch overwrites it
+    if (lane < c64) {
+      const int64_t grow = r0 + (int64_t)defRow[r0 + b0 + lane];
+      om = draw_full((int)nvec[grow] /* (int) n(i), Logit.hpp:287 */, defPsi[r0 + b0 + lane], seed, idx0 + (uint64_t)grow, epoch, status);
+      if (w) w[grow] = om;
+    }
+    sOm[wave][lane] = om;                                   // 0 past the end of the list
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int sub = 0; 16 * sub < c64; ++sub) {
+      const int s = sub & 1;
+      if (16 * (sub + 1) < c64) {
+        gather(b0 + 16 * (sub + 1), s ^ 1);
+        BL_WAIT_VM(8);                                      // all but the eight pieces just issued
+      } else {
+        BL_WAIT_VM(0);
+      }
+      asm volatile("" ::: "memory");
+      mfma_tile(acc, &sTile[wave][s][0], oB, sOm[wave][16 * sub + 4 * gq + k], lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the slot is read out before it is overwritten
+    }
   }
   if (stats && lane == 0 && cnt) atomicAdd(stats, (unsigned long long)cnt);
-  block_reduce_store(acc, reinterpret_cast<double (*)[kNAcc][64]>(&sTile[0][0]), partial, lane, wave);
+  __syncthreads();
+  block_reduce_store(acc, reinterpret_cast<double (*)[kNAcc][64]>(&sTile[0][0][0]), partial, lane, wave);
 }
 
 // PP = sum over workgroups (fixed order) of the slabs [36][64]; instruction id = (m, n, r), lane (i, blk, j) holds

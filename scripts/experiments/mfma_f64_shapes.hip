@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k(double* out, unsigned long long* clk, i
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       if (SHAPE == 16) acc16[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc16[i], 0, 0, 0);
-      if (SHAPE == 4) acc4[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, L ? lp[64 * (i % 16)] : b, acc4[i], 0, 0, 0);
+      if (SHAPE == 4) acc4[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, L ? lp[64 * ((i + it) % 16)] : b, acc4[i], 0, 0, 0);
 #pragma unroll
       for (int j = 0; j < F; ++j) f[j] = __builtin_fma(f[j], b, a);
     }

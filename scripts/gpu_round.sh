@@ -29,12 +29,13 @@ find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | while read f; do
 grep -h "^{" gpurun_out/bench.log | tail -1 > gpurun_out/bench_line_$TAG.json
 fi
 if [[ $PHASE == *b* ]]; then
-rm -rf gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_valu_$TAG gpurun_out/pmc_stall_$TAG
-PARGS="--steps 2 --warmup 1 --gibbs-sweeps 3 --gibbs-chain 0 --no-cpu"
+rm -rf gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_valu_$TAG gpurun_out/pmc_stall_$TAG gpurun_out/pmc_mfma_$TAG
+PARGS="--steps 2 --warmup 1 --gibbs-sweeps 3 --gibbs-chain 0 --no-cpu --c5 --c5-sweeps 2 --mlogit-n 0"
 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch_$TAG -- python3 bench.py $PARGS
 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write_$TAG -- python3 bench.py $PARGS
 step pmc_valu 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_valu_$TAG -- python3 bench.py $PARGS
 step pmc_stall 400 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_stall_$TAG -- python3 bench.py $PARGS
+step pmc_mfma 400 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_mfma_$TAG -- python3 bench.py $PARGS
 python3 scripts/summarize_pmc.py $TAG > gpurun_out/pmc_summary_$TAG.txt 2>&1
 cat gpurun_out/pmc_summary_$TAG.txt | cut -c1-300
 fi

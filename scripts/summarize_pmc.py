@@ -20,6 +20,12 @@ MI355X_MICROARCH.md, rocprofv3 PMC slots: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST
   active_inst_frac       = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES an instruction of the wave executing
   salu_per_valu          = SQ_INSTS_SALU / SQ_INSTS_VALU
   lds_conflict_frac      = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+and, from the "mfma" pass:
+  mfma_insts_per_launch  = SQ_INSTS_MFMA (wave-level matrix instructions)
+  mfma_busy_frac         = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x gpu cycles of that pass, SQ_BUSY_CYCLES / 32): the counter
+                           adds 64 cycles per v_mfma_f64_16x16x4_f64 and 16 per v_mfma_f64_4x4x4_4b_f64 (nominal pass counts:
+                           the measured issue intervals are 101.7 and 12.4 cycles, scripts/experiments/mfma_f64_shapes.hip)
+  lds_insts_per_launch   = SQ_INSTS_LDS
 """
 import collections
 import csv
@@ -31,7 +37,7 @@ tag = sys.argv[1]
 KEEP = ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce", "k_sweep")
 SIMDS = 256 * 4
 summary = collections.defaultdict(dict)
-for kind in ("fetch", "write", "valu", "stall"):
+for kind in ("fetch", "write", "valu", "stall", "mfma"):
     files = glob.glob(f"gpurun_out/pmc_{kind}_{tag}/**/*counter_collection.csv", recursive=True)
     if not files:
         print(kind, "no counter file")
@@ -80,6 +86,11 @@ for name, m in summary.items():
             e["salu_per_valu"] = m.get("SQ_INSTS_SALU", 0.0) / m["SQ_INSTS_VALU"]
         if m.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+    if "SQ_INSTS_MFMA" in m:
+        e["mfma_insts_per_launch"] = m["SQ_INSTS_MFMA"]
+        e["lds_insts_per_launch"] = m.get("SQ_INSTS_LDS", 0.0)
+        if m.get("SQ_BUSY_CYCLES"):
+            e["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * m["SQ_BUSY_CYCLES"] / 32.0)
     out[short] = e
 with open(f"gpurun_out/pmc_summary_{tag}.json", "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
