@@ -840,8 +840,7 @@ void launch_nb_big_x(const blk::SweepPlan& plan, const double* tX, const double*
   constexpr size_t lds = (2 * 16 * (size_t)(P + 16) + 2 * 16) * sizeof(double);
   if (parts & 1) launch_draw_pass<NB, EXACT>(plan, tX, n, beta, off, w, N, seed, epoch, idx0, mode, status, s);
   if (!(parts & 2)) return;
-  static const bool big_mfma = getenv("BL_XWX_BIG_MFMA") != nullptr;   // development aid: the 16x16x4 kernel below
-  if (!big_mfma && EXACT && N > 0) {      // P = 128 / 256: the small matrix instruction (kernels_xwx4.hip)
+  if (EXACT && N > 0) {      // P = 128 / 256: the small matrix instruction (kernels_xwx4.hip); padded P: the kernel below
     blk::launch_xwx_q4_big(plan.nblocks, NB, tX, w, N, partial, PP, s);
     return;
   }

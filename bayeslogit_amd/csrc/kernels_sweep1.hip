@@ -6,14 +6,13 @@
 // queue wants hundreds of rows per wave while the rows wait on chip.  Here a wave takes 16 rows at a time and
 // removes the queue instead; and X' Omega X goes through the SMALL fp64 matrix instruction:
 //
-//   * v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 512 flops) issues every 12.4 cycles on gfx950,
-//     v_mfma_f64_16x16x4_f64 (2048 flops) every 101.7: 102 against 49.5 TFLOP/s (scripts/experiments/
-//     mfma_f64_shapes.hip).  Lane (K = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3) holds A_blk[e][K],
+//   * v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, 512 flops) sustains 75 TFLOP/s on gfx950 (one per
+//     16.5 cycles per SIMD), v_mfma_f64_16x16x4_f64 (2048 flops) 48 (one per ~101): scripts/gpu_mfma_rates.py.  Lane (K = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3) holds A_blk[e][K],
 //     B_blk[K][e] and D_blk[K][e] (scripts/experiments/mfma_f64_4x4_layout.hip).  With K = row of a 4-row group,
 //     A_m = omega x (columns 16m + 4 blk + e) and B_n^r = x (columns 16n + 4 ((blk + r) & 3) + e), instruction
 //     (m, n, r) adds the four 4x4 blocks PP[16m + 4blk + .][16n + 4((blk + r) & 3) + .]; 36 of them (m <= n; r = 0..3
 //     for m < n; r = 0, 1, 2 for m = n) cover the upper triangle of the 16 x 16 grid of 4x4 blocks: 36 accumulator
-//     doubles per lane, 144 matrix instructions per 16 rows = 1786 cycles against 3840 for the 40 big ones;
+//     doubles per lane, 144 matrix instructions per 16 rows = 2380 cycles against 4040 for the 40 big ones;
 //   * a tile lives in LDS, row r at 512 r, its four 128-byte column chunks swapped pairwise in odd rows
 //     (chunk n at 128 (n ^ (r & 1))): every B_n^r is then one conflict-free ds_read_b64 (the two rows a half-wave
 //     reads sit in opposite halves of the 256-byte bank window), and the rotation r costs no vector instruction.

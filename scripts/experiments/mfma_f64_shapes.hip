@@ -6,6 +6,9 @@
 //   (c) the 4x4x4 loop with its B operand read from LDS by one ds_read_b64 per matrix instruction (the P = 256 kernel's mix);
 //   (b) the 16x16x4 loop with F independent v_fma_f64 per matrix instruction in the same wave: if the vector FMAs ran
 //       in the matrix instruction's shadow the cycles per iteration would stay put; they add up instead.
+// The cycle counts are each wave's own (s_memtime around its loop) divided by the waves per SIMD: the waves of a SIMD are
+// not in step, so the absolute figures flatter both instructions (event-timed rates: scripts/gpu_mfma_rates.py: 48 and
+// 75 TFLOP/s); the comparisons between variants hold.
 // Build here (hipcc cross-compiles), run on the GPU box:  scripts/experiments/mfma_f64_shapes
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -94,6 +97,9 @@ int main()
   run<4, 16, 2>(2, it);
   run<4, 16, 4>(2, it);
   run<16, 0 + 1, 0>(1, it);
+  run<4, 64, 0>(2, it);
+  run<4, 16, 0>(4, it);
+  run<16, 10, 0>(4, it);
   run<4, 16, 0, 1>(2, it);
   run<4, 16, 0, 1>(4, it);
   run<4, 32, 0, 1>(2, it);
