@@ -23,6 +23,8 @@ struct SweepPlan {
   int nb = 0;             // fused: P/16
   int ntile = 0;          // generic: number of 64x64 output tiles (upper triangle)
   size_t partial_doubles = 0;   // workspace size
+  int single_pass = -1;         // P = 64: -1 follow bl_set_sweep_mode, 0 two passes, 1 one pass (a handle turns it off when most
+                                // of its rows leave the single pass's fast path: bl_gibbs_sweep_local)
 };
 SweepPlan make_plan(int64_t N, int P, int num_cus);
 
@@ -43,6 +45,8 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
 // PPpart in another (fixed) summation order.  ws: sweep_once64_ws_doubles(nblocks, N) doubles (make_plan sizes the
 // plan's workspace for it); stats (or nullptr): += the number of rows that left the fast path.
 size_t sweep_once64_ws_doubles(int nblocks, int64_t N);
+// device counter inside that workspace: rows the second kernel drew, accumulated over the sweeps since it was last zeroed
+unsigned long long* sweep_once64_deferred_counter(double* ws, int nblocks, int64_t N);
 void launch_sweep_once64(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
                          double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s);

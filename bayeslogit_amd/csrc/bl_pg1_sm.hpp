@@ -240,6 +240,9 @@ BL_HD int pg1_stage_verdict(const Pg1Staged& s, double u2)
   const bool ok = u2 <= s.A * (1.0 - kSmRatioMax) || u2 <= s.A * (1.0 - s.r3);
   return inner ? (ok ? 1 : 2) : 0;
 }
+// The stages in order.  STRAIGHT: no branch at all; otherwise a_1/a_0 (an exponential) is evaluated only when some lane of
+// the wave has u2 within kSmRatioMax of its threshold, as pg1_decide does -- same verdicts, same X.
+template <bool STRAIGHT = false>
 BL_HD int pg1_attempt_small_known(bool fresh, double Z, double fz, double mass, double u1, double u2, double& X)
 {
   Pg1Staged s;
@@ -247,9 +250,15 @@ BL_HD int pg1_attempt_small_known(bool fresh, double Z, double fz, double mass, 
   pg1_stage_log(s);
   pg1_stage_x(s, Z, fz);
   pg1_stage_A(s);
-  pg1_stage_r3(s);
   X = s.X;
-  return pg1_stage_verdict(s, u2);
+  if (STRAIGHT) {
+    pg1_stage_r3(s);
+    return pg1_stage_verdict(s, u2);
+  }
+  const bool inner = !(u2 > s.A);
+  bool ok = u2 <= s.A * (1.0 - kSmRatioMax);
+  if (pg1_any(inner && !ok)) ok = ok || u2 <= s.A * (1.0 - 3.0 * bl_exp(s.rarg));
+  return inner ? (ok ? 1 : 2) : 0;
 }
 
 // One attempt: consume the block (u1, u2).  Returns true when a draw has completed; the draw is

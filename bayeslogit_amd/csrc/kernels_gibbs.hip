@@ -943,7 +943,7 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
     return;
   }
   if (plan.fused == 1 && plan.P == 64 && mode == W_DRAW && !off && parts == 3 && !xoc && N > 0 &&
-      blh::sweep_single_pass()) {
+      (plan.single_pass < 0 ? blh::sweep_single_pass() : plan.single_pass)) {
     // X read once (kernels_sweep1.hip); omega is stored only if the caller wants it
     launch_sweep_once64(plan.nblocks, tX, n, beta, w_store, N, partial, PPpart, seed, epoch, idx0, status,
                         blh::sweep_stats(), s);

@@ -203,15 +203,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
 
   // tile at `base`: HBM -> registers (rows past r1 read the range's last row; their weight is 0) ...
   auto load_tile = [&](v2d (&R)[8], double& nn, int64_t base) __attribute__((always_inline)) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t row = base + 4 * g + k;
-      const double* p = tX + (size_t)(row < r1 ? row : r1 - 1) * 64 + 2 * c;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) R[2 * g + h] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + 32 * h));
-    }
     const int64_t myrow = base + 4 * gq + k;               // n of the row this lane draws travels with the tile
-    nn = __builtin_nontemporal_load(nvec + (myrow < r1 ? myrow : r1 - 1));
+    if (base + 16 <= r1) {                                 // (wave-uniform) a whole tile: one address, immediates
+      const double* p = tX + (size_t)(base + k) * 64 + 2 * c;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          R[2 * g + h] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + 256 * g + 32 * h));
+      nn = __builtin_nontemporal_load(nvec + myrow);
+    } else {                                               // the range's last tile, and the load past it: rows clamped
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = base + 4 * g + k;
+        const double* p = tX + (size_t)(row < r1 ? row : r1 - 1) * 64 + 2 * c;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) R[2 * g + h] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + 32 * h));
+      }
+      nn = __builtin_nontemporal_load(nvec + (myrow < r1 ? myrow : r1 - 1));
+    }
   };
   // ... -> slot s
   auto store_tile = [&](const v2d (&R)[8], int s) __attribute__((always_inline)) {
@@ -322,7 +332,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __
                                                                 const uint32_t* __restrict__ defRow,
                                                                 const double* __restrict__ defPsi,
                                                                 const uint32_t* __restrict__ defCnt,
-                                                                unsigned long long* __restrict__ stats)
+                                                                unsigned long long* __restrict__ stats,
+                                                                unsigned long long* __restrict__ hstats)
 {
   __shared__ __attribute__((aligned(16))) char sTile[kBlock / 64][2][8192];   // (the first 36 KB: scratch of the reduction)
   __shared__ double sOm[kBlock / 64][64];
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __
     }
   }
   if (stats && lane == 0 && cnt) atomicAdd(stats, (unsigned long long)cnt);
+  if (lane == 0 && cnt) atomicAdd(hstats, (unsigned long long)cnt);      // the handle's own count (fall-back policy)
   __syncthreads();
   block_reduce_store(acc, reinterpret_cast<double (*)[kNAcc][64]>(&sTile[0][0][0]), partial, lane, wave);
 }
@@ -426,6 +438,13 @@ size_t sweep_once64_ws_doubles(int nblocks, int64_t N)
   return (size_t)nblocks * 2 * kNAcc * 64 + n + (n + 1) / 2 + (size_t)nblocks * 2 + 8;
 }
 
+unsigned long long* sweep_once64_deferred_counter(double* ws, int nblocks, int64_t N)
+{
+  const size_t n = (size_t)(N > 0 ? N : 0);
+  // behind the slabs, psi, row offsets (n uint32 = (n + 1) / 2 doubles) and counts (4 nblocks uint32 = 2 nblocks doubles)
+  return reinterpret_cast<unsigned long long*>(ws + (size_t)nblocks * 2 * kNAcc * 64 + n + (n + 1) / 2 + (size_t)nblocks * 2);
+}
+
 void launch_sweep_once64(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
                          double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s)
@@ -435,10 +454,11 @@ void launch_sweep_once64(int nblocks, const double* tX, const double* n, const d
   double* defPsi = slabs + (size_t)nblocks * 2 * kNAcc * 64;
   uint32_t* defRow = reinterpret_cast<uint32_t*>(defPsi + nn);
   uint32_t* defCnt = defRow + 2 * ((nn + 1) / 2);
+  unsigned long long* hstats = sweep_once64_deferred_counter(ws, nblocks, N);
   hipLaunchKernelGGL(k_sweep_once64, dim3(nblocks), dim3(kBlock), 0, s, tX, n, beta, w, N, seed, epoch, idx0, slabs, defRow,
                      defPsi, defCnt);
   hipLaunchKernelGGL(k_sweep_deferred64, dim3(nblocks), dim3(kBlock), 0, s, tX, n, w, N, seed, epoch, idx0,
-                     slabs + (size_t)nblocks * kNAcc * 64, status, defRow, defPsi, defCnt, stats);
+                     slabs + (size_t)nblocks * kNAcc * 64, status, defRow, defPsi, defCnt, stats, hstats);
   hipLaunchKernelGGL(k_reduce_q4, dim3(kNAcc), dim3(1024), 0, s, slabs, 2 * nblocks, PP);
 }
 

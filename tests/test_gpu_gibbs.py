@@ -192,6 +192,34 @@ def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale):
         assert nd1 >= (n != 1).sum()
 
 
+def test_single_pass_gives_way_when_most_rows_are_deferred(gpu, oracle):
+    """Rare-event-like data (most |psi| > 3.1: the other left-piece sampler) leaves the single pass's fast path; the handle
+    looks at its count of deferred rows after its 8th sweep and goes back to the two passes (bl_gibbs_sweep_local).  A
+    handle whose rows stay on the fast path does not.  omega is the oracle's either way."""
+    from bayeslogit_amd import device as D
+    N, P = 40000, 64
+    X, y, n = synth(N, P, 77)
+    for scale, falls_back in ((8.0, True), (0.5, False)):
+        beta0 = np.linspace(-1.0, 1.0, P) * scale
+        g = shard_of(X, y, n, gpu, seed=13, idx0=5)
+        w = torch.zeros(N, dtype=torch.float64, device=gpu)
+        counts = []
+        for s_ in range(10):
+            g.set_beta(beta0)
+            D.sweep_deferred_rows()
+            g.sweep_local(s_, w)
+            D.sync_status()
+            counts.append(D.sweep_deferred_rows())
+        assert all(c > 0 for c in counts[:8]), counts
+        assert (counts[8] == 0 and counts[9] == 0) == falls_back, counts
+        if falls_back:
+            assert min(counts[:8]) > 0.2 * N
+        _, wo = oracle.sweep_partial(X, n, beta0, 13, 9, 5)
+        rel = np.abs(w.cpu().numpy() - wo) / np.abs(wo)
+        assert (rel > 1e-10).sum() <= 1e-5 * N + 1, rel.max()
+        g.close()
+
+
 def test_kernel_paths_agree_on_padded_data(gpu):
     """The same data with zero columns appended takes different kernels: P = 64 the register-tile MFMA
     kernels on 16-byte loads, P = 63+1 zero... P = 65 the LDS-tile MFMA kernel with masked 8-byte loads
