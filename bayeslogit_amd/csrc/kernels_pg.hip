@@ -13,32 +13,29 @@ constexpr int kBlock = 256;        // 4 wavefronts
 constexpr int kMaxBlocks = 256 * 8;  // 256 CUs x 8 resident blocks, grid-stride beyond
 
 // ---------------------------------------------------------------- rpg_devroye
-// Wavefront work queue, one launch per sampler class: |z|/2 < 1/t and |z|/2 >= 1/t take different
-// left-piece samplers (PolyaGamma.cpp:87 vs :103); a launch contains the code of ONE class and
-// skips the observations of the other, so the light class runs at 3 waves/SIMD without carrying
-// the heavy one's registers.  Each wave owns chunks of kChunk consecutive observations.
-//   phase 1 (all 64 lanes busy): coalesced load of z, the observations of this launch's class
-//            COMPACTED into an index list (ballot + prefix popcount) and their proposal mass staged
-//            in LDS (class 1: a 12-term polynomial in z^2 computed in the same sweep; class 2: two
-//            Chebyshev sums, evaluated over the compacted list so that all lanes are busy); z and
-//            n are staged too, so a lane starting an observation waits on nothing from HBM;
-//   phase 2: the attempt body of bl_pg1_sm.hpp under the work queue of bl_pg1_queue.hpp.  A lane
-//            whose draw has completed takes the next unstarted observation of the list (idle lanes
-//            found with __ballot, numbered with a prefix popcount); lanes still inside a draw when
-//            the list runs out stay IN FLIGHT while the wave builds the next chunk's list, so the
-//            queue drains once per launch, not once per chunk.
-// The stream belongs to the observation, so which lane draws it, and when, does not change the
-// result.
-// This file is built with machine-LICM off (bayeslogit_amd/build.py): hoisting the attempt body's fp64 polynomial
-// constants out of the queue loop held 168 / 256 registers per lane (3 / 2 waves per SIMD); without it the two
-// kernels take 68 / 78, and six workgroups per CU are resident (LDS: 22.5 KB per workgroup at 256-observation
-// chunks).  Measured on C2: 2.39 -> 2.16 ms per 1e8 draws (chunk 512 at 3 per CU: 2.33; 256 at 5 / 6 / 7: 2.24 / 2.17 /
-// 2.18; 128 at 8, registers capped at 64: 2.83).
+// Wavefront work queue.  |z|/2 < 1/t and |z|/2 >= 1/t take different left-piece samplers (PolyaGamma.cpp:87 vs :103): two
+// attempt bodies, two index lists per chunk, ONE launch (round 1 and most of round 2 used one launch per class: z was read
+// and classified twice; 45.5 against 46.8 G draws/s on the same box).  Each wave owns chunks of kChunk consecutive
+// observations.
+//   phase 1 (all 64 lanes busy): coalesced load of z (the chunk's loads issued before the first is used), the observations
+//            COMPACTED by class into two index lists (ballot + prefix popcount) and their proposal mass staged in LDS
+//            (class 1: a 12-term polynomial in z^2 computed in the same sweep; class 2: two Chebyshev sums, evaluated
+//            over its compacted list so that all lanes are busy); z and n are staged too, so a lane starting an
+//            observation waits on nothing from HBM;
+//   phase 2: the attempt bodies of bl_pg1_sm.hpp under the work queue of bl_pg1_queue.hpp, one class after the other.  A
+//            lane whose draw has completed takes the next unstarted observation of the list (idle lanes found with
+//            __ballot, numbered with a prefix popcount); lanes still inside a draw when a list runs out stay IN FLIGHT
+//            (one in-flight slot per class and lane) while the wave goes on, so each queue drains once per launch, not
+//            once per chunk.
+// The stream belongs to the observation, so which lane draws it, and when, does not change the result.
+// This file is built with machine-LICM off (bayeslogit_amd/build.py): hoisting the attempt bodies' fp64 polynomial
+// constants out of the queue loop held 168 / 256 registers per lane in the per-class kernels (3 / 2 waves per SIMD);
+// without it they took 68 / 78, and this kernel, with both bodies and two in-flight slots, 94: five workgroups per CU
+// (six: 80 registers + 80 bytes of scratch, 42 G draws/s).  LDS: 24 KB per workgroup at 256-observation chunks.
 constexpr int kChunk = 256;                          // observations per wave per chunk
-constexpr int kDevOcc1 = 6, kDevOcc2 = 6;            // resident workgroups per CU of the two class launches
 
-template <int CLS>
-__global__ __launch_bounds__(kBlock, CLS == 1 ? kDevOcc1 : kDevOcc2) void k_rpg_devroye(double* __restrict__ x,
+constexpr int kDevOcc = 5;                           // resident workgroups per CU (94 registers; 6 spills: 42 G draws/s)
+__global__ __launch_bounds__(kBlock, kDevOcc) void k_rpg_devroye(double* __restrict__ x,
                                                                           const int* __restrict__ nvec, int nscalar,
                                                                           const double* __restrict__ z, int64_t num,
                                                                           uint64_t seed, uint32_t epoch, uint64_t idx0,
@@ -47,72 +44,71 @@ __global__ __launch_bounds__(kBlock, CLS == 1 ? kDevOcc1 : kDevOcc2) void k_rpg_
   __shared__ double sM[kBlock / 64][kChunk];
   __shared__ double sZ[kBlock / 64][kChunk];
   __shared__ int sN[kBlock / 64][kChunk];
-  __shared__ unsigned short sIdx[kBlock / 64][kChunk];
+  __shared__ unsigned short sIdx1[kBlock / 64][kChunk];
+  __shared__ unsigned short sIdx2[kBlock / 64][kChunk];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const int64_t nchunks = (num + kChunk - 1) / kChunk;
   int st_flags = 0;
-  Pg1Slot L;           // this lane's in-flight observation
+  Pg1Slot L1, L2;      // this lane's in-flight observation of either class
   for (int64_t ch = (int64_t)blockIdx.x * (kBlock / 64) + wave; ch < nchunks; ch += (int64_t)gridDim.x * (kBlock / 64)) {
     const int64_t base = ch * kChunk;
     const int cnt = (int)((num - base) < kChunk ? (num - base) : kChunk);
-    int nL = 0;        // wave-uniform list length
-    // all of the chunk's loads are issued before the first is used (one 512-byte load in flight per
-    // wave made this phase latency-bound)
-    constexpr int LB = CLS == 1 ? 4 : 8;   // loads in flight per lane (register budget of the class)
-#pragma unroll 1
-    for (int j0 = 0; j0 < kChunk / 64; j0 += LB) {
-      if (j0 * 64 >= cnt) break;
-      double zk[LB];
-      int nk[LB];
+    int n1 = 0, n2 = 0;       // wave-uniform list lengths
+    double zk[kChunk / 64];
+    int nk[kChunk / 64];
 #pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        const int k = (j0 + j) * 64 + lane;
-        zk[j] = k < cnt ? z[base + k] : 0.0;
-        nk[j] = nvec ? (k < cnt ? nvec[base + k] : 0) : nscalar;
-      }
+    for (int j = 0; j < kChunk / 64; ++j) {
+      const int k = j * 64 + lane;
+      zk[j] = k < cnt ? z[base + k] : 0.0;
+      nk[j] = nvec ? (k < cnt ? nvec[base + k] : 0) : nscalar;
+    }
 #pragma unroll
-      for (int j = 0; j < LB; ++j) {
-        const int k = (j0 + j) * 64 + lane;
-        bool mine = false;
-        if (k < cnt) {
-          const int n = nk[j];
-          if (n == 0) {
-            if (CLS == 1) x[base + k] = 0.0;           // LogitWrapper.cpp:74-77
-          } else {
-            const double Z = fabs(zk[j]) * 0.5;        // PolyaGamma.cpp:154
-            mine = (kSmTRecip > Z) == (CLS == 1);      // PolyaGamma.cpp:87
-            sZ[wave][k] = zk[j];
-            sN[wave][k] = n;
-            if (CLS == 1 && mine) sM[wave][k] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);
-          }
+    for (int j = 0; j < kChunk / 64; ++j) {
+      const int k = j * 64 + lane;
+      bool m1 = false, m2 = false;
+      if (k < cnt) {
+        const int n = nk[j];
+        if (n == 0) {
+          x[base + k] = 0.0;                           // LogitWrapper.cpp:74-77
+        } else {
+          const double Z = fabs(zk[j]) * 0.5;          // PolyaGamma.cpp:154
+          m1 = kSmTRecip > Z;                          // PolyaGamma.cpp:87
+          m2 = !m1;
+          sZ[wave][k] = zk[j];
+          sN[wave][k] = n;
+          if (m1) sM[wave][k] = pg1_mass_small(Z, kSmPiSq8 + 0.5 * Z * Z);
         }
-        const uint64_t mm = __ballot(mine);
-        if (mine) sIdx[wave][nL + __popcll(mm & lt_mask)] = (unsigned short)k;
-        nL += __popcll(mm);
+      }
+      const uint64_t b1 = __ballot(m1), b2 = __ballot(m2);
+      if (m1) sIdx1[wave][n1 + __popcll(b1 & lt_mask)] = (unsigned short)k;
+      if (m2) sIdx2[wave][n2 + __popcll(b2 & lt_mask)] = (unsigned short)k;
+      n1 += __popcll(b1);
+      n2 += __popcll(b2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < n2; i0 += 64) {               // class 2's mass over its compacted list
+      const int i = i0 + lane;
+      if (i < n2) {
+        const int k = sIdx2[wave][i];
+        const double Z = fabs(sZ[wave][k]) * 0.5;
+        sM[wave][k] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (CLS == 2) {
-      for (int i0 = 0; i0 < nL; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < nL) {
-          const int k = sIdx[wave][i];
-          const double Z = fabs(sZ[wave][k]) * 0.5;
-          sM[wave][k] = pg1_mass(Z, kSmPiSq8 + 0.5 * Z * Z);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    devroye_queue_run<CLS, 2, int, true>(L, false, &sIdx[wave][0], nL, sZ[wave], sM[wave], x, sN[wave], 1, base, idx0,
-                                         epoch, k0, k1, lt_mask, st_flags);
+    devroye_queue_run<1, 2, int, true>(L1, false, &sIdx1[wave][0], n1, sZ[wave], sM[wave], x, sN[wave], 1, base, idx0, epoch,
+                                       k0, k1, lt_mask, st_flags);
+    devroye_queue_run<2, 2, int, true>(L2, false, &sIdx2[wave][0], n2, sZ[wave], sM[wave], x, sN[wave], 1, base, idx0, epoch,
+                                       k0, k1, lt_mask, st_flags);
     __builtin_amdgcn_wave_barrier();
   }
-  devroye_queue_run<CLS, 2, int, true>(L, true, nullptr, 0, nullptr, nullptr, x, nullptr, 1, 0, idx0, epoch, k0, k1,
-                                       lt_mask, st_flags);
+  devroye_queue_run<1, 2, int, true>(L1, true, nullptr, 0, nullptr, nullptr, x, nullptr, 1, 0, idx0, epoch, k0, k1, lt_mask,
+                                     st_flags);
+  devroye_queue_run<2, 2, int, true>(L2, true, nullptr, 0, nullptr, nullptr, x, nullptr, 1, 0, idx0, epoch, k0, k1, lt_mask,
+                                     st_flags);
   if (st_flags) atomicOr(status, st_flags);
 }
 
@@ -348,12 +344,9 @@ int bl_rpg_devroye_dev(double* x, const int* n_vec, int n_scalar, const double* 
   if (int rc = check_args(x, z, num)) return rc;
   if (num == 0) return BL_OK;
   hipStream_t s = (hipStream_t)stream;
-  // one launch per sampler class, each sized to its resident grid (3 resp. 2 workgroups per CU)
   const int64_t wg_chunks = (num + 4 * kChunk - 1) / (4 * kChunk);
-  hipLaunchKernelGGL(k_rpg_devroye<1>, dim3(blh::grid_for(wg_chunks, 1, 256 * kDevOcc1)), dim3(kBlock), 0, s, x, n_vec,
-                     n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
-  hipLaunchKernelGGL(k_rpg_devroye<2>, dim3(blh::grid_for(wg_chunks, 1, 256 * kDevOcc2)), dim3(kBlock), 0, s, x, n_vec,
-                     n_scalar, z, num, seed, epoch, idx0, blh::status_word(s));
+  hipLaunchKernelGGL(k_rpg_devroye, dim3(blh::grid_for(wg_chunks, 1, 256 * kDevOcc)), dim3(kBlock), 0, s, x, n_vec, n_scalar, z,
+                     num, seed, epoch, idx0, blh::status_word(s));
   BL_HIP_TRY(hipGetLastError());
   return BL_OK;
 }
