@@ -211,7 +211,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
             st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
     if (st[7]) fprintf(stderr, "  moves redone move by move: %llu; shader clock over the sweeps: %.0f MHz\n", st[8],
                        (double)(st[10] - st[9]) / ((st[6] - st[7]) / 100.0));
-    if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups\n", st[8], st[12]);
+    if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups (blocks through the three tests), %llu segments taken again behind an exact move\n", st[8], st[12], st[13]);
     if (st[19]) fprintf(stderr, "  shader cycles: sweeps %llu = segment set-up %llu + blocks that passed %llu + blocks with an exact move %llu + rest\n",
                         st[19], st[16], st[17], st[18]);
     if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu\n", st[20], st[21], st[22]);

@@ -1801,6 +1801,442 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
   }
 #undef BL_FETCH_SEG
 }
+
+// ---- the row-split sweeps again, with the speculative unit a whole SEGMENT of 64 moves (k_beta_sweeps_split: blocks of 16,
+// one barrier each) and little but the dependent chain left in it:
+//   * the scan tables (the coordinate of move i of scan k) come from k_beta_scan_tables in global memory; a lane holds the
+//     column offsets of the segment after next (loaded two segments ahead), so fetching a move's column of L is one
+//     v_readlane and one buffer load (row offset in a register, column offset as the scalar offset);
+//   * the two column sets (this segment's, the next one's) swap roles from segment to segment: no register copies;
+//   * the cheap test (k_beta_sweeps_split's: the whole of [-2.51, 2.51] and s feasible for the row, three FMAs and an OR
+//     per row and move) runs on whole blocks of 16 with the sign bits OR-ed per block; (dz, z_c) reach the wave as uniform
+//     operands through the wave's own LDS slot (broadcast reads, half a block ahead of the arithmetic); the four
+//     wavefronts meet once per segment (one word each);
+//   * a block that fails (or is cut by the end of the scan) runs k_beta_sweeps_split's three tests from the chain value
+//     the cheap pass left at its start; a move that fails those is redone with its exact bounds (split_exact), the rest of
+//     its block goes through the three tests again and the blocks behind it through a new cheap pass.
+// Same decisions as k_beta_sweeps_split up to the rounding of the tests' left-hand sides; same arithmetic for beta_j.
+template <int H>      // H: half-block of 8 moves
+__device__ __forceinline__ void run_load(const double* zw, double (&dz)[8], double (&z1)[8])
+{
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double2 v = *reinterpret_cast<const double2*>(zw + 2 * (8 * H + u));
+    dz[u] = v.x;
+    z1[u] = v.y;
+  }
+}
+template <int H>
+__device__ __forceinline__ void run_calc(const double (&l1)[64], const double (&dz)[8], const double (&z1)[8], double& bs,
+                                         uint32_t& acc)
+{
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double l = l1[8 * H + u];
+    const double g = fma(-l, z1[u], bs);        // beta_j + L (p - z_c) at p = 0
+    double e;                                   // ... at the worse end of [-2.51, 2.51] (by hand: the compiler would keep
+    asm("v_fma_f64 %0, -|%1|, %2, %3" : "=v"(e) : "v"(l), "s"(2.51), "v"(g));   // |l| of the whole segment in registers)
+    bs = fma(l, dz[u], bs);                     // ... at p = s: beta_j after the move
+    acc |= (uint32_t)__double2hiint(e) | (uint32_t)__double2hiint(bs);
+  }
+}
+
+// What a move redone with its exact bounds reads from memory (requested as soon as the move is known)
+struct ExactIn {
+  double l1, rl, rh, r0, r1, r2, r3;
+};
+
+// Half-block H (moves 8 H .. 8 H + 7) of a segment the slow way: k_beta_sweeps_split's three sufficient tests from the
+// chain value bs at its start (a move before `start` carries dz = 0 in the wave's LDS slot and is not tested).  Returns the
+// mask of the moves that fail all three somewhere in the matrix (wave-uniform, the same in every wave) and, in bb, the
+// chain value just before the first of them (after the half-block if there is none); for that move the exact path's
+// inputs are requested into x.
+template <int H>
+__device__ __forceinline__ uint32_t run_half(const double (&l1seg)[64], double bs, bool lastrow, int lane, int wave,
+                                             int start, int mcnt, const double* zw, uint32_t* x1, unsigned& par,
+                                             const double* __restrict__ Lg, const double* __restrict__ Rg,
+                                             const double* __restrict__ Rh, const double* __restrict__ RkSeg, int P, int jr,
+                                             int cq, int g4, double& bb, ExactIn& x)
+{
+  const int lo_m = start > 8 * H ? start : 8 * H, hi_m = mcnt < 8 * H + 8 ? mcnt : 8 * H + 8;
+  const uint32_t valid = hi_m <= lo_m ? 0u : (((1u << (hi_m - 8 * H)) - 1u) & ~((1u << (lo_m - 8 * H)) - 1u));
+  double dz[8], z1[8];
+  run_load<H>(zw, dz, z1);
+  uint32_t pA = 0, pB = 0, pC = 0;
+  double b = bs;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double l1 = l1seg[8 * H + u];
+    const double g = fma(-l1, z1[u], b);                             // beta_j + L (p - z_c) at p = 0
+    const double es = fma(l1, dz[u], b);                             //                      at p = s: beta_j after the move
+    const double e1 = fma(l1, -2.51, g), e2 = fma(l1, -1.26, g), e3 = fma(l1, 1.26, g), e4 = fma(l1, 2.51, g);
+    const uint32_t hs = (uint32_t)__double2hiint(es), h0 = (uint32_t)__double2hiint(g);
+    pA |= ((hs | (uint32_t)__double2hiint(e2) | (uint32_t)__double2hiint(e3)) >> 31) << u;          // (1.26, 1.26)
+    pB |= ((hs | h0 | (uint32_t)__double2hiint(e4)) >> 31) << (8 + u);                              // (0, 2.51)
+    pC |= ((hs | (uint32_t)__double2hiint(e1) | h0) >> 31) << (16 + u);                             // (2.51, 0)
+    b = es;
+  }
+  uint32_t pk = lastrow ? 0u : (pA | pB | pC);                       // row P-1 is not constrained (Logit.hpp:383: j < P-1)
+  pk = wave_or_u32(pk);
+  uint32_t* slot = x1 + par * 4;
+  if (lane == 0) slot[wave] = pk & (valid * 0x010101u);
+  __syncthreads();
+  const uint4 sv = *reinterpret_cast<const uint4*>(slot);
+  par ^= 1u;
+  const uint32_t m = sv.x | sv.y | sv.z | sv.w;
+  const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m & (m >> 8) & (m >> 16) & 0xFFu));
+  int n = 8;
+  if (f != 0u) {
+    n = __builtin_ctz(f);
+    const int c = __builtin_amdgcn_readlane(cq, 8 * H + n);
+    const size_t off = (size_t)c * P + jr;
+    x.l1 = Lg[off];
+    x.rl = Rg[off];
+    x.rh = Rh[off];
+    const double* Rn = RkSeg + (size_t)(8 * H + n) * kRec + g4;
+    x.r0 = Rn[0];
+    x.r1 = Rn[1];
+    x.r2 = Rn[2];
+    x.r3 = Rn[3];
+  }
+  b = bs;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (u < n) b = fma(l1seg[8 * H + u], dz[u], b);
+  bb = b;
+  return f;
+}
+
+// move mf of the segment with its exact bounds (Logit.hpp:383-397), its inputs in x: split_exact's arithmetic
+__device__ __forceinline__ void run_exact(const ExactIn& x, int mf, int cq, double z1q, int lane, int wave, int nq,
+                                          double& bj, double* sz, double* xl, unsigned& par)
+{
+  const int c = __builtin_amdgcn_readlane(cq, mf);
+  const double z1 = readlane_f64(z1q, mf);
+  double lo = z1 - bj * x.rl, hi = z1 - bj * x.rh;   // NaN: this row does not bound the move on that side
+  wave_maxmin(lo, hi);
+  double* sl = xl + par * 8;
+  if (lane == 0) {
+    sl[wave * 2] = lo;
+    sl[wave * 2 + 1] = hi;
+  }
+  __syncthreads();
+  double glo = -__builtin_huge_val(), ghi = __builtin_huge_val();
+  for (int w = 0; w < nq; ++w) {
+    glo = vmax64(glo, sl[w * 2]);            // v_max_f64 / v_min_f64 return the other operand for a NaN
+    ghi = vmin64(ghi, sl[w * 2 + 1]);
+  }
+  par ^= 1u;
+  const double z2 = tnorm_lanes(x.r0, x.r1, x.r2, x.r3, lane, glo, ghi);
+  bj += x.l1 * (z2 - z1);
+  if (wave == 0 && lane == 0) sz[c] = z2;
+}
+
+// Scan tables for k_beta_sweeps_run: tab[k P + i] = coordinate of move i of scan k.  Scan k applies its P-1 swaps to the
+// order scan k-1 left (Logit.hpp:375-377: the permutation persists), i.e. order_k = g_0 o g_1 o ... o g_k with g_k the
+// scan's own swaps on the identity: a prefix product, taken here in log2 P doubling steps over two LDS copies.
+__global__ __launch_bounds__(1024) void k_beta_scan_tables(blk::BetaArgs a)
+{
+  extern __shared__ unsigned char tb8[];
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  const int* swp = reinterpret_cast<const int*>(rec + (size_t)P * P * kRec);
+  uint32_t* tab = reinterpret_cast<uint32_t*>(const_cast<double*>(rec) + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P);
+  unsigned char* A = tb8;
+  unsigned char* Bf = tb8 + (size_t)P * P;
+  if (t < P) {
+    unsigned char* sg = A + t * P;
+    for (int i = 0; i < P; ++i) sg[i] = (unsigned char)i;
+    for (int i = 0; i < P - 1; ++i) {
+      const int j = swp[t * (P - 1) + i];
+      const unsigned char tmp = sg[i];
+      sg[i] = sg[j];
+      sg[j] = tmp;
+    }
+  }
+  __syncthreads();
+  for (int d = 1; d < P; d <<= 1) {
+    for (int e = t; e < P * P; e += nthr) {
+      const int k = e / P;
+      const unsigned char v = A[e];
+      Bf[e] = k >= d ? A[(k - d) * P + v] : v;
+    }
+    __syncthreads();
+    unsigned char* tmp = A;
+    A = Bf;
+    Bf = tmp;
+  }
+  for (int e = t; e < P * P + 128; e += nthr) tab[e] = e < P * P ? (uint32_t)A[e] : 0u;
+}
+
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+
+template <int NQ>
+__global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
+{
+  extern __shared__ double lds[];
+  if (*a.status & ST_NOT_PD) return;       // see k_beta
+  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
+  const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
+  const double* zz = a.work + 2 * (size_t)P * P + P;               // z
+  const double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
+  const double* __restrict__ Rh = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;   // 1/L where L < 0, else NaN
+  const uint32_t* __restrict__ tab = reinterpret_cast<const uint32_t*>(Rh + (size_t)P * P);
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int Pe = (P + 1) & ~1;                                   // 16-byte alignment of what follows
+  double* sz = lds;                                              // z (P)
+  uint32_t* xm = reinterpret_cast<uint32_t*>(sz + Pe);           // [2][4 waves][4]: a block's three test masks
+  double* xl = sz + Pe + 16;                                     // [2][4 waves][2]: a move's bound candidates
+  uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16);           // [2][4 waves]: a segment's cheap verdicts
+  double* zw = xl + 16 + 4 + 128 * wave;                         // [4 waves][64][2]: the wave's (dz, z_c), read back uniform
+  for (int j = t; j < P; j += nthr) sz[j] = zz[j];
+  if (t < 8) x1[t] = 0u;
+  __syncthreads();
+
+  const int j = 64 * wave + lane;
+  const int jr = j < P ? j : P - 1;          // a lane past the matrix rides on row P-1, which no test looks at
+  const bool lastrow = jr == P - 1;
+  double bj = j < P ? a.beta_prev[j] : 0.0;
+  const int g4 = (lane < 5 ? lane : 0) * 4;
+  const uint32_t jr8 = (uint32_t)jr * 8u, P8 = (uint32_t)P * 8u;
+  unsigned par = 0;
+  int spec_on = 1;      // (kept wave-uniform by hand: a branch the compiler takes for divergent drags the exact path's waits into the fast one)
+  // L is lower triangular: the rows of wave w are zero in the columns from 64 (w + 1) on.  The buffer ends there, and a load
+  // past the end of a buffer returns zero without going to memory (3/8 of the loads of P = 256)
+  const int ncol = 64 * (wave + 1) < P ? 64 * (wave + 1) : P;
+  const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Lg), (short)0, (int)((uint32_t)ncol * P8), 0x00020000);
+  const int nseg = (P + 63) / 64;            // segments per scan (<= NQ)
+  const int total = P * nseg;
+  // per lane, one and two segments ahead: the coordinate of move `lane` (its column offset, for the fetch) and its first normal
+  int cq_n, cq_nn, co_n;
+  double sq_n;
+#define BL_TABLE(dst, gg)             /* lane i: coordinate of move i of segment gg (scan gg / nseg, moves 64 (gg % nseg) ...) */ \
+  {                                                                                                                         \
+    const int kk_ = (gg) / nseg, qq_ = (gg) - kk_ * nseg;                                                                   \
+    dst = ((gg) < total && lane < P - 64 * qq_) ? (int)tab[(size_t)kk_ * P + 64 * qq_ + lane] : 0;                          \
+  }
+#define BL_FETCH_HEAD(gg)             /* segment gg's normals; its column offsets (coordinates in cq_n) */                  \
+  {                                                                                                                         \
+    const int kk_ = (gg) / nseg, qq_ = (gg) - kk_ * nseg;                                                                   \
+    sq_n = ((gg) < total && lane < P - 64 * qq_) ? rec[((size_t)kk_ * P + 64 * qq_ + lane) * kRec + 3] : 0.0;               \
+    co_n = cq_n * (int)P8;                                                                                                  \
+  }
+#define BL_FETCH_GROUP(dst, G_)       /* eight column offsets to scalars, then eight loads */                               \
+  {                                                                                                                         \
+    int so_[8];                                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) so_[u] = __builtin_amdgcn_readlane(co_n, 8 * (G_) + u);                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                         \
+      const v2u32 v_ = __builtin_amdgcn_raw_buffer_load_b64(Lrs, (int)jr8, so_[u], 0);                                      \
+      dst[8 * (G_) + u] = __hiloint2double((int)v_.y, (int)v_.x);                                                           \
+    }                                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  }
+#define BL_FETCH_ALL(dst)                                                                                                   \
+  {                                                                                                                         \
+    BL_FETCH_GROUP(dst, 0) BL_FETCH_GROUP(dst, 1) BL_FETCH_GROUP(dst, 2) BL_FETCH_GROUP(dst, 3)                             \
+    BL_FETCH_GROUP(dst, 4) BL_FETCH_GROUP(dst, 5) BL_FETCH_GROUP(dst, 6) BL_FETCH_GROUP(dst, 7)                             \
+  }
+#define BL_NOFETCH(dst, G_)
+  const bool prof = a.dbg != nullptr;
+  unsigned long long nexact = 0, ncareful = 0, nrepass = 0;
+  long long tPass = 0, tSlow = 0, tAll = prof ? clock64() : 0;
+  int nslow = 0;
+
+  // one cheap pass over the whole half-blocks h0 .. nbw-1 of the segment: the chain value at the end (bs) and at the
+  // half-blocks' starts (cp1..cp7; one not run leaves the value as it is), the half-blocks that failed somewhere in the
+  // matrix (Fb, the same in every wave)
+#define BL_CALC(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                         \
+    if ((h0) <= (H) && nbw > (H)) run_calc<H>(cur, dX, zX, bs, aX);                                                         \
+    FETCH(nxt, H)
+#define BL_PASS(cur, h0, FETCH, nxt)                                                                                        \
+  {                                                                                                                         \
+    double dA[8], zA[8], dB[8], zB[8];                                                                                      \
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;                                                \
+    bs = bj;                                                                                                                \
+    run_load<0>(zw, dA, zA);                                                                                                \
+    run_load<1>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 0, dA, zA, a0, FETCH, nxt)                                                                             \
+    cp1 = bs;                                                                                                               \
+    run_load<2>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 1, dB, zB, a1, FETCH, nxt)                                                                             \
+    cp2 = bs;                                                                                                               \
+    run_load<3>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 2, dA, zA, a2, FETCH, nxt)                                                                             \
+    cp3 = bs;                                                                                                               \
+    run_load<4>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 3, dB, zB, a3, FETCH, nxt)                                                                             \
+    cp4 = bs;                                                                                                               \
+    run_load<5>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 4, dA, zA, a4, FETCH, nxt)                                                                             \
+    cp5 = bs;                                                                                                               \
+    run_load<6>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 5, dB, zB, a5, FETCH, nxt)                                                                             \
+    cp6 = bs;                                                                                                               \
+    run_load<7>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    BL_CALC(cur, h0, 6, dA, zA, a6, FETCH, nxt)                                                                             \
+    cp7 = bs;                                                                                                               \
+    BL_CALC(cur, h0, 7, dB, zB, a7, FETCH, nxt)                                                                             \
+    uint32_t vb = (a0 >> 31) | ((a1 >> 31) << 1) | ((a2 >> 31) << 2) | ((a3 >> 31) << 3) | ((a4 >> 31) << 4) |             \
+                  ((a5 >> 31) << 5) | ((a6 >> 31) << 6) | ((a7 >> 31) << 7);                                                \
+    if (lastrow) vb = 0u;                                                                                                   \
+    vb = wave_or_u32(vb);                                                                                                   \
+    uint32_t* slot1 = x1 + par * 4;                                                                                         \
+    if (lane == 0) slot1[wave] = vb;                                                                                        \
+    __syncthreads();                                                                                                        \
+    const uint4 sv = *reinterpret_cast<const uint4*>(slot1);                                                                \
+    par ^= 1u;                                                                                                              \
+    Fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w)) | tailbit;                              \
+  }
+#define BL_HALF(H, cp)                                                                                                      \
+    f = run_half<H>(cur_, start <= 8 * (H) ? cp : bj, lastrow, lane, wave, start, mcnt, zw, x1, par, Lg, Rg, Rh, RkSeg, P,  \
+                    jr, cq, g4, bb, xin);
+  // one segment: `cur` holds its columns, `nxt` receives the next segment's
+#define BL_SEGMENT(cur, nxt, g, k, q)                                                                                       \
+  {                                                                                                                         \
+    const int m0 = 64 * (q);                                                                                                \
+    const int mcnt = (P - m0) < 64 ? (P - m0) : 64;                                                                         \
+    const double* RkSeg = rec + ((size_t)(k) * P + m0) * kRec;                                                              \
+    const bool has = lane < mcnt;                                                                                           \
+    /* what the last segment fetched has had a segment's time to land: say so before the next fetch is issued, or the */    \
+    /* in-order load counter makes every later use of it wait for the new fetch instead */                                  \
+    __builtin_amdgcn_s_waitcnt(0x0F70);     /* vmcnt(0) */                                                                  \
+    const int cq = cq_n;                                                                                                    \
+    const double sq = sq_n;                                                                                                 \
+    cq_n = cq_nn;                                                                                                           \
+    const double z1q = has ? sz[cq] : 0.0;                                                                                  \
+    const double dzq = has ? sq - z1q : 0.0;                                                                                \
+    *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(dzq, z1q);                                                    \
+    BL_TABLE(cq_nn, (g) + 2)                                                                                                \
+    BL_FETCH_HEAD((g) + 1)         /* (past the last segment: column 0 again, harmless) */                                  \
+    WAVE_SYNC();                                                                                                            \
+    if (!spec_on) {                                                                                                         \
+      BL_FETCH_ALL(nxt)                                                                                                     \
+      for (int i = 0; i < mcnt; ++i) split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, NQ, i, cq, z1q, bj, sz, xl, par, g4); \
+      nslow += mcnt;                                                                                                        \
+    } else {                                                                                                                \
+      const int nbw = mcnt >> 3;                                      /* whole half-blocks */                               \
+      const uint32_t tailbit = (mcnt & 7) ? (1u << nbw) : 0u;         /* the one the scan's end cuts: the slow way */       \
+      double bs, cp1, cp2, cp3, cp4, cp5, cp6, cp7;                                                                         \
+      uint32_t Fb;                                                                                                          \
+      /* the first pass in line (a loop header here would wait for the fetch just issued); what follows it is rare */       \
+      const long long tp0 = prof ? clock64() : 0;                                                                           \
+      BL_PASS(cur, 0, BL_FETCH_GROUP, nxt)   /* the next segment's columns are requested between the half-blocks */         \
+      if (prof) tPass += clock64() - tp0;                                                                                   \
+      unsigned long long exm = 0ull;                                  /* moves redone exactly (they wrote their own z) */   \
+      if (Fb == 0u) {                                                                                                       \
+        bj = bs;                                                                                                            \
+      } else {                                                                                                              \
+        const long long ts0 = prof ? clock64() : 0;                                                                         \
+        const double (&cur_)[64] = cur;                                                                                     \
+        int start = 0;                                                                                                      \
+        bool dirty = false;            /* a move was redone since the last cheap pass: its verdicts behind that move are void */ \
+        for (;;) {                                                                                                          \
+          if (Fb == 0u) {                                                                                                   \
+            bj = bs;                                                                                                        \
+            break;                                                                                                          \
+          }                                                                                                                 \
+          const int Hf = __builtin_ctz(Fb);                                                                                 \
+          const int bend = mcnt < 8 * Hf + 8 ? mcnt : 8 * Hf + 8;                                                           \
+          uint32_t f;                                                                                                       \
+          double bb;                                                                                                        \
+          ExactIn xin;                                                                                                      \
+          if (prof) ++ncareful;                                                                                             \
+          switch (Hf) {                                                                                                     \
+            case 0: BL_HALF(0, bj) break;                                                                                   \
+            case 1: BL_HALF(1, cp1) break;                                                                                  \
+            case 2: BL_HALF(2, cp2) break;                                                                                  \
+            case 3: BL_HALF(3, cp3) break;                                                                                  \
+            case 4: BL_HALF(4, cp4) break;                                                                                  \
+            case 5: BL_HALF(5, cp5) break;                                                                                  \
+            case 6: BL_HALF(6, cp6) break;                                                                                  \
+            default: BL_HALF(7, cp7) break;                                                                                 \
+          }                                                                                                                 \
+          bj = bb;                                                                                                          \
+          if (f != 0u) {                           /* the first move that needs its bounds */                               \
+            const int mf = 8 * Hf + __builtin_ctz(f);                                                                       \
+            run_exact(xin, mf, cq, z1q, lane, wave, NQ, bj, sz, xl, par);                                                   \
+            exm |= 1ull << mf;                                                                                              \
+            nslow = __builtin_amdgcn_readfirstlane(nslow + 1);                                                              \
+            dirty = true;                                                                                                   \
+            start = mf + 1;                                                                                                 \
+            if (start < bend) {                    /* the rest of the half-block: the tests again, behind the move */       \
+              if (lane >= 8 * Hf && lane <= mf) zw[2 * lane] = 0.0;                                                         \
+              WAVE_SYNC();                                                                                                  \
+              continue;                                                                                                     \
+            }                                                                                                               \
+          }                                                                                                                 \
+          start = bend;                                                                                                     \
+          Fb &= ~(1u << Hf);                                                                                                \
+          if (start >= mcnt) break;                /* that was the segment's last half-block: bj is the chain's end */      \
+          if (!dirty) continue;                    /* the chain is as the cheap pass had it: its other verdicts stand */    \
+          if (prof) ++nrepass;                                                                                              \
+          BL_PASS(cur, Hf + 1, BL_NOFETCH, nxt)    /* the half-blocks behind the redone move again, from its chain value */ \
+          dirty = false;                                                                                                    \
+        }                                                                                                                   \
+        if (prof) tSlow += clock64() - ts0;                                                                                 \
+      }                                                                                                                     \
+      if (wave == 0 && has && !((exm >> lane) & 1ull)) sz[cq] = sq;                                                         \
+    }                                                                                                                       \
+  }
+
+  double colA[64], colB[64];
+  BL_TABLE(cq_n, 0)
+  BL_TABLE(cq_nn, 1)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  BL_FETCH_HEAD(0)
+  BL_FETCH_ALL(colA)
+  int k = 0, q = 0;
+  for (int g = 0; g < total; g += 2) {
+    BL_SEGMENT(colA, colB, g, k, q)
+    if (++q == nseg) {
+      q = 0;
+      spec_on = __builtin_amdgcn_readfirstlane((3 * nslow < P || ((k + 1) & 7) == 0) ? 1 : 0);   // a chain pressed against its bounds: every move exactly; look again every 8th scan
+      nexact += (unsigned long long)nslow;
+      nslow = 0;
+      ++k;
+      __syncthreads();         // the scan's z are in LDS before the next scan gathers them
+    }
+    if (g + 1 < total) {
+      BL_SEGMENT(colB, colA, g + 1, k, q)
+      if (++q == nseg) {
+        q = 0;
+        spec_on = __builtin_amdgcn_readfirstlane((3 * nslow < P || ((k + 1) & 7) == 0) ? 1 : 0);
+        nexact += (unsigned long long)nslow;
+        nslow = 0;
+        ++k;
+        __syncthreads();
+      }
+    }
+  }
+  if (j < P) a.beta_out[j] = bj;
+  if (prof && t == 0) {
+    a.dbg[8] += nexact;
+    a.dbg[12] += ncareful;
+    a.dbg[13] += nrepass;
+    a.dbg[19] = (unsigned long long)(clock64() - tAll);
+    a.dbg[16] = 0ull;
+    a.dbg[17] = (unsigned long long)tPass;
+    a.dbg[18] = (unsigned long long)tSlow;
+  }
+#undef BL_SEGMENT
+#undef BL_HALF
+#undef BL_PASS
+#undef BL_CALC
+#undef BL_NOFETCH
+#undef BL_FETCH_ALL
+#undef BL_FETCH_GROUP
+#undef BL_FETCH_HEAD
+#undef BL_TABLE
+}
 #undef L_
 
 }  // namespace
@@ -1811,16 +2247,18 @@ size_t beta_work_doubles(int P)
 {
   size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
   if (P > 64 && P <= 256)    // constrained_sweeps_wide: tnorm records + swap targets after the dense stage's matrices
-    generic += (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P;   // + the second reciprocal matrix
+    generic += (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P +   // + the second reciprocal matrix
+               ((size_t)P * P + 128 + 1) / 2;                                     // + the scan tables (u32, 128 entries of slack)
   const size_t small = (size_t)P * P * kRec + 2 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
   return generic > small ? generic : small;
 }
 
-// BL_BETA_SPLIT=0: the one-wavefront sweeps (k_beta_sweeps) instead of the row-split ones, for comparison
-static bool beta_split_off()
+// BL_BETA_SPLIT=0: the one-wavefront sweeps (k_beta_sweeps); =1: the row-split sweeps in blocks of 16 (k_beta_sweeps_split);
+// default: the row-split sweeps in segments of 64 (k_beta_sweeps_run).  For comparison: all three give the same beta.
+static int beta_split_mode()
 {
-  static const bool off = [] { const char* e = getenv("BL_BETA_SPLIT"); return e && e[0] == '0'; }();
-  return off;
+  static const int m = [] { const char* e = getenv("BL_BETA_SPLIT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+  return m;
 }
 
 void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
@@ -1837,6 +2275,12 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   // P > 64: factor (one workgroup) -> inverse (a workgroup per 64 columns) -> finish (one workgroup) [-> sweeps]
   const bool wide = mode == B_CONSTRAINED && a.P <= 256;
   if (wide) hipLaunchKernelGGL(k_beta_records, dim3(64), dim3(256), 0, s, a);
+  if (wide && beta_split_mode() == 2) {
+    const size_t lt = 2 * (size_t)a.P * a.P;
+    if (lt > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_beta_scan_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt);
+    hipLaunchKernelGGL(k_beta_scan_tables, dim3(1), dim3(1024), lt, s, a);
+  }
   hipLaunchKernelGGL(k_beta_factor, dim3(1), dim3(kDenseThreads), 0, s, a, mode);
   if (mode == B_SOLVE || mode == B_MVN) return;
   {
@@ -1850,7 +2294,12 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   }
   hipLaunchKernelGGL(k_beta_finish, dim3(1), dim3(kDenseThreads), lds, s, a, mode);
   if (wide) lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;   // the one-wavefront sweeps' LDS
-  if (wide && !beta_split_off()) {
+  if (wide && beta_split_mode() == 2) {
+    const size_t l2 = ((((size_t)a.P + 1) & ~(size_t)1) + 16 + 16 + 4 + 512) * 8;
+    const int nq = (a.P + 63) / 64;
+    auto fn = nq == 2 ? k_beta_sweeps_run<2> : nq == 3 ? k_beta_sweeps_run<3> : k_beta_sweeps_run<4>;
+    hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), l2, s, a);
+  } else if (wide && beta_split_mode() == 1) {
     const size_t l2 = ((size_t)a.P + 32 + 128 + 4) * 8 + (size_t)a.P * a.P;
     const int nq = (a.P + 63) / 64;
     auto fn = nq == 2 ? k_beta_sweeps_split<2> : nq == 3 ? k_beta_sweeps_split<3> : k_beta_sweeps_split<4>;

@@ -1,5 +1,7 @@
 """The replicated P x P stage alone (PP + P0, Cholesky, beta draw) on posteriors of the shape a chain sees.
-    python scripts/gpu_beta.py P [P ...]        (BL_BETA_SPLIT=0: the one-wavefront sweeps for 64 < P <= 256)"""
+    python scripts/gpu_beta.py P [P ...]        (BL_BETA_SPLIT=0 / 1: the one-wavefront sweeps / the 16-move blocks for 64 < P <= 256)
+The digest printed per line covers every bit of the six draws' beta: equal digests across BL_BETA_SPLIT settings = same chain."""
+import hashlib
 import sys
 import time
 
@@ -21,6 +23,7 @@ for P in [int(v) for v in sys.argv[1:]] or [64, 128, 256]:
     ppd, bpd, bd = t(np.asfortranarray(PPsum).ravel(order="F")), t(bP), t(bprev)
     for con in (1, 0):
         ms = []
+        dig = hashlib.sha1()
         for s in range(6):
             g.pp().copy_(ppd); g.bp().copy_(bpd); g.beta().copy_(bd)
             torch.cuda.synchronize()
@@ -28,6 +31,7 @@ for P in [int(v) for v in sys.argv[1:]] or [64, 128, 256]:
             g.draw_beta(s, con)
             torch.cuda.synchronize()
             ms.append((time.perf_counter() - t0) * 1e3)
-        print(f"P={P} constrain={con}: {np.median(ms[1:]):.3f} ms  beta[:3]={g.beta()[:3].cpu().numpy()}")
+            dig.update(g.beta().cpu().numpy().tobytes())
+        print(f"P={P} constrain={con}: {np.median(ms[1:]):.3f} ms  beta[:3]={g.beta()[:3].cpu().numpy()} digest={dig.hexdigest()[:12]}")
     D.sync_status()
     g.close()
