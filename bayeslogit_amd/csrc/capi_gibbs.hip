@@ -214,7 +214,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
     if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups (blocks through the three tests), %llu segments taken again behind an exact move\n", st[8], st[12], st[13]);
     if (st[19]) fprintf(stderr, "  shader cycles: sweeps %llu = segment set-up %llu + blocks that passed %llu + blocks with an exact move %llu + rest\n",
                         st[19], st[16], st[17], st[18]);
-    if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu\n", st[20], st[21], st[22]);
+    if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu  (segments of 64: exact moves %llu, passes taken again %llu)\n", st[20], st[21], st[22], st[20], st[21]);
     if (st[11]) fprintf(stderr, "  random inputs generated (waves 1-3) after %.1f us\n", (st[11] - st[0]) / 100.0);
     if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }

@@ -1308,16 +1308,34 @@ __device__ void constrained_wide_reciprocals(const blk::BetaArgs& a, const doubl
   }
 }
 
+// Two words per chain behind the scan tables of k_beta_sweeps_run (zero when the chain is created): [0] = 1 while the chain
+// is pressed against its bounds (most moves need them: the one-wavefront sweeps below, which have no barrier per move,
+// are then twice as fast as the row-split ones), [1] = k_beta_sweeps_run's verdict on the draw it has just made.
+__device__ __forceinline__ uint32_t* beta_mode_word(const blk::BetaArgs& a)
+{
+  const size_t P = (size_t)a.P;
+  double* rec = a.work + 2 * P * P + 2 * P;
+  return reinterpret_cast<uint32_t*>(rec + P * P * kRec + (P * P + 1) / 2 + P * P) + P * P + 128;
+}
+
 // The sweeps themselves: one 4-wave workgroup (512 registers per lane available: the pipeline's register
 // sets do not spill), launched behind k_beta on the same stream.  Reads L, 1/L, z from k_beta's scratch.
 template <int RPL>
-__global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
+__global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a, bool paired)
 {
   extern __shared__ double lds[];
   // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
   // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
   if (*a.status & ST_NOT_PD) return;
   const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
+  // paired: launched behind k_beta_sweeps_run (launch_beta); the chain's mode word says which of the two takes this draw
+  uint32_t* mode = paired ? beta_mode_word(a) : nullptr;
+  const uint32_t pressed = paired ? mode[0] : 1u;
+  __syncthreads();                           // every thread has read the word before thread 0 rewrites it
+  if (pressed == 0u) {                       // k_beta_sweeps_run has made the draw and left its verdict in mode[1]
+    if (t == 0) mode[0] = mode[1];
+    return;
+  }
   const int nrec = P * kRec;
   const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
   const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
@@ -1353,6 +1371,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
   const int lane = t & 63;
   const bool serial = t < 64;
   const double inf = __builtin_huge_val();
+  int nbound = 0;              // moves that needed their bounds (wave-uniform)
   double bj[RPL];
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
@@ -1441,6 +1460,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
                   __ballot(lo > l2s || hi < h0s) == 0ull)) {
               wave_maxmin(lo, hi);
               z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+              ++nbound;
             }
             const double dz = z2 - z1;
 #pragma unroll
@@ -1459,6 +1479,8 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a)
       const int j = lane + 64 * r;
       if (j < P) a.beta_out[j] = bj[r];
     }
+    // still pressed against its bounds?  (a sixth of the moves needing them; k_beta_sweeps_run hands over at a third)
+    if (paired && lane == 0) mode[0] = (6 * nbound >= P * P) ? 1u : 0u;
   }
 }
 
@@ -1841,32 +1863,62 @@ __device__ __forceinline__ void run_calc(const double (&l1)[64], const double (&
   }
 }
 
+// the same with the test's half-width per move (2.51, or 0 for a move that is not to be tested: with dz = z_c = 0 it then
+// changes nothing and passes): the cheap pass taken again behind a move redone exactly, whose half-block is partly done
+template <int H>
+__device__ __forceinline__ void run_load_k(const double* zk, double (&kk)[8])
+{
+#pragma unroll
+  for (int u = 0; u < 8; u += 2) {
+    const double2 v = *reinterpret_cast<const double2*>(zk + 8 * H + u);
+    kk[u] = v.x;
+    kk[u + 1] = v.y;
+  }
+}
+template <int H>
+__device__ __forceinline__ void run_calc_k(const double (&l1)[64], const double (&dz)[8], const double (&z1)[8],
+                                           const double (&kk)[8], double& bs, uint32_t& acc)
+{
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double l = l1[8 * H + u];
+    const double g = fma(-l, z1[u], bs);
+    double e;
+    asm("v_fma_f64 %0, -|%1|, %2, %3" : "=v"(e) : "v"(l), "v"(kk[u]), "v"(g));
+    bs = fma(l, dz[u], bs);
+    acc |= (uint32_t)__double2hiint(e) | (uint32_t)__double2hiint(bs);
+  }
+}
+
 // What a move redone with its exact bounds reads from memory (requested as soon as the move is known)
 struct ExactIn {
-  double l1, rl, rh, r0, r1, r2, r3;
+  double l1, r0, r1, r2, r3;
 };
 
-// Half-block H (moves 8 H .. 8 H + 7) of a segment the slow way: k_beta_sweeps_split's three sufficient tests from the
+// Half-block H (moves 8 H .. 8 H + 7; its entries of L copied to l8: one body of code for the eight, the path is rare and
+// its code cold) of a segment the slow way: k_beta_sweeps_split's three sufficient tests from the
 // chain value bs at its start (a move before `start` carries dz = 0 in the wave's LDS slot and is not tested).  Returns the
 // mask of the moves that fail all three somewhere in the matrix (wave-uniform, the same in every wave) and, in bb, the
 // chain value just before the first of them (after the half-block if there is none); for that move the exact path's
-// inputs are requested into x.
-template <int H>
-__device__ __forceinline__ uint32_t run_half(const double (&l1seg)[64], double bs, bool lastrow, int lane, int wave,
+// inputs go into x (its tnorm record is requested here, its entry of L is in the registers).
+__device__ __forceinline__ uint32_t run_half(const double (&l8)[8], int H, double bs, bool lastrow, int lane, int wave,
                                              int start, int mcnt, const double* zw, uint32_t* x1, unsigned& par,
-                                             const double* __restrict__ Lg, const double* __restrict__ Rg,
-                                             const double* __restrict__ Rh, const double* __restrict__ RkSeg, int P, int jr,
-                                             int cq, int g4, double& bb, ExactIn& x)
+                                             const double* __restrict__ RkSeg, int g4, double& bb, ExactIn& x)
 {
   const int lo_m = start > 8 * H ? start : 8 * H, hi_m = mcnt < 8 * H + 8 ? mcnt : 8 * H + 8;
   const uint32_t valid = hi_m <= lo_m ? 0u : (((1u << (hi_m - 8 * H)) - 1u) & ~((1u << (lo_m - 8 * H)) - 1u));
   double dz[8], z1[8];
-  run_load<H>(zw, dz, z1);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double2 v = *reinterpret_cast<const double2*>(zw + 2 * (8 * H + u));
+    dz[u] = v.x;
+    z1[u] = v.y;
+  }
   uint32_t pA = 0, pB = 0, pC = 0;
   double b = bs;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const double l1 = l1seg[8 * H + u];
+    const double l1 = l8[u];
     const double g = fma(-l1, z1[u], b);                             // beta_j + L (p - z_c) at p = 0
     const double es = fma(l1, dz[u], b);                             //                      at p = s: beta_j after the move
     const double e1 = fma(l1, -2.51, g), e2 = fma(l1, -1.26, g), e3 = fma(l1, 1.26, g), e4 = fma(l1, 2.51, g);
@@ -1888,11 +1940,6 @@ __device__ __forceinline__ uint32_t run_half(const double (&l1seg)[64], double b
   int n = 8;
   if (f != 0u) {
     n = __builtin_ctz(f);
-    const int c = __builtin_amdgcn_readlane(cq, 8 * H + n);
-    const size_t off = (size_t)c * P + jr;
-    x.l1 = Lg[off];
-    x.rl = Rg[off];
-    x.rh = Rh[off];
     const double* Rn = RkSeg + (size_t)(8 * H + n) * kRec + g4;
     x.r0 = Rn[0];
     x.r1 = Rn[1];
@@ -1900,20 +1947,28 @@ __device__ __forceinline__ uint32_t run_half(const double (&l1seg)[64], double b
     x.r3 = Rn[3];
   }
   b = bs;
+  double lsel = 0.0;                           // the redone move's entry of L: in the registers already
 #pragma unroll
-  for (int u = 0; u < 8; ++u)
-    if (u < n) b = fma(l1seg[8 * H + u], dz[u], b);
+  for (int u = 0; u < 8; ++u) {
+    if (u < n) b = fma(l8[u], dz[u], b);
+    if (u == n) lsel = l8[u];
+  }
+  x.l1 = lsel;
   bb = b;
   return f;
 }
 
 // move mf of the segment with its exact bounds (Logit.hpp:383-397), its inputs in x: split_exact's arithmetic
-__device__ __forceinline__ void run_exact(const ExactIn& x, int mf, int cq, double z1q, int lane, int wave, int nq,
-                                          double& bj, double* sz, double* xl, unsigned& par)
+__device__ __forceinline__ void run_exact(const ExactIn& x, int mf, int cq, double z1q, bool lastrow, int lane, int wave,
+                                          int nq, double& bj, double* sz, double* xl, unsigned& par)
 {
   const int c = __builtin_amdgcn_readlane(cq, mf);
   const double z1 = readlane_f64(z1q, mf);
-  double lo = z1 - bj * x.rl, hi = z1 - bj * x.rh;   // NaN: this row does not bound the move on that side
+  // constrained_wide_reciprocals' tables, made here from the entry of L (the same IEEE quotient; a table read would put an L2
+  // round trip at the head of the move)
+  const double rcp = 1.0 / x.l1, nan = __builtin_nan("");
+  const double rl = (x.l1 > 0.0 && !lastrow) ? rcp : nan, rh = (x.l1 < 0.0 && !lastrow) ? rcp : nan;
+  double lo = z1 - bj * rl, hi = z1 - bj * rh;       // NaN: this row does not bound the move on that side
   wave_maxmin(lo, hi);
   double* sl = xl + par * 8;
   if (lane == 0) {
@@ -1976,6 +2031,8 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
 {
   extern __shared__ double lds[];
   if (*a.status & ST_NOT_PD) return;       // see k_beta
+  uint32_t* mode = beta_mode_word(a);
+  if (mode[0] != 0u) return;               // a chain pressed against its bounds: k_beta_sweeps, launched behind, takes the draw
   const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
   const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
   const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
@@ -1990,6 +2047,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
   double* xl = sz + Pe + 16;                                     // [2][4 waves][2]: a move's bound candidates
   uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16);           // [2][4 waves]: a segment's cheap verdicts
   double* zw = xl + 16 + 4 + 128 * wave;                         // [4 waves][64][2]: the wave's (dz, z_c), read back uniform
+  double* zk = xl + 16 + 4 + 512 + 64 * wave;                    // [4 waves][64]: the test's half-width per move (a pass taken again)
   for (int j = t; j < P; j += nthr) sz[j] = zz[j];
   if (t < 8) x1[t] = 0u;
   __syncthreads();
@@ -2041,8 +2099,8 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
 #define BL_NOFETCH(dst, G_)
   const bool prof = a.dbg != nullptr;
   unsigned long long nexact = 0, ncareful = 0, nrepass = 0;
-  long long tPass = 0, tSlow = 0, tAll = prof ? clock64() : 0;
-  int nslow = 0;
+  long long tPass = 0, tSlow = 0, tExact = 0, tRepass = 0, tAll = prof ? clock64() : 0;
+  int nslow = 0, noff = 0;     // moves of the scan redone exactly; scans in which a third of the moves were
 
   // one cheap pass over the whole half-blocks h0 .. nbw-1 of the segment: the chain value at the end (bs) and at the
   // half-blocks' starts (cp1..cp7; one not run leaves the value as it is), the half-blocks that failed somewhere in the
@@ -2050,7 +2108,13 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
 #define BL_CALC(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                         \
     if ((h0) <= (H) && nbw > (H)) run_calc<H>(cur, dX, zX, bs, aX);                                                         \
     FETCH(nxt, H)
-#define BL_PASS(cur, h0, FETCH, nxt)                                                                                        \
+#define BL_CALC_K(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                       \
+    if ((h0) <= (H) && nbw > (H)) {                                                                                         \
+      double kk_[8];                                                                                                        \
+      run_load_k<H>(zk, kk_);                                                                                               \
+      run_calc_k<H>(cur, dX, zX, kk_, bs, aX);                                                                              \
+    }
+#define BL_PASS(cur, h0, CALC, FETCH, nxt)                                                                                  \
   {                                                                                                                         \
     double dA[8], zA[8], dB[8], zB[8];                                                                                      \
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;                                                \
@@ -2058,33 +2122,33 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     run_load<0>(zw, dA, zA);                                                                                                \
     run_load<1>(zw, dB, zB);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 0, dA, zA, a0, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 0, dA, zA, a0, FETCH, nxt)                                                                                \
     cp1 = bs;                                                                                                               \
     run_load<2>(zw, dA, zA);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 1, dB, zB, a1, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 1, dB, zB, a1, FETCH, nxt)                                                                                \
     cp2 = bs;                                                                                                               \
     run_load<3>(zw, dB, zB);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 2, dA, zA, a2, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 2, dA, zA, a2, FETCH, nxt)                                                                                \
     cp3 = bs;                                                                                                               \
     run_load<4>(zw, dA, zA);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 3, dB, zB, a3, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 3, dB, zB, a3, FETCH, nxt)                                                                                \
     cp4 = bs;                                                                                                               \
     run_load<5>(zw, dB, zB);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 4, dA, zA, a4, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 4, dA, zA, a4, FETCH, nxt)                                                                                \
     cp5 = bs;                                                                                                               \
     run_load<6>(zw, dA, zA);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 5, dB, zB, a5, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 5, dB, zB, a5, FETCH, nxt)                                                                                \
     cp6 = bs;                                                                                                               \
     run_load<7>(zw, dB, zB);                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    BL_CALC(cur, h0, 6, dA, zA, a6, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 6, dA, zA, a6, FETCH, nxt)                                                                                \
     cp7 = bs;                                                                                                               \
-    BL_CALC(cur, h0, 7, dB, zB, a7, FETCH, nxt)                                                                             \
+    CALC(cur, h0, 7, dB, zB, a7, FETCH, nxt)                                                                                \
     uint32_t vb = (a0 >> 31) | ((a1 >> 31) << 1) | ((a2 >> 31) << 2) | ((a3 >> 31) << 3) | ((a4 >> 31) << 4) |             \
                   ((a5 >> 31) << 5) | ((a6 >> 31) << 6) | ((a7 >> 31) << 7);                                                \
     if (lastrow) vb = 0u;                                                                                                   \
@@ -2097,8 +2161,10 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     Fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w)) | tailbit;                              \
   }
 #define BL_HALF(H, cp)                                                                                                      \
-    f = run_half<H>(cur_, start <= 8 * (H) ? cp : bj, lastrow, lane, wave, start, mcnt, zw, x1, par, Lg, Rg, Rh, RkSeg, P,  \
-                    jr, cq, g4, bb, xin);
+    {                                                                                                                       \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) l8[u] = cur_[8 * (H) + u];                                              \
+      bs0 = start <= 8 * (H) ? cp : bj;                                                                                     \
+    }
   // one segment: `cur` holds its columns, `nxt` receives the next segment's
 #define BL_SEGMENT(cur, nxt, g, k, q)                                                                                       \
   {                                                                                                                         \
@@ -2129,7 +2195,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
       uint32_t Fb;                                                                                                          \
       /* the first pass in line (a loop header here would wait for the fetch just issued); what follows it is rare */       \
       const long long tp0 = prof ? clock64() : 0;                                                                           \
-      BL_PASS(cur, 0, BL_FETCH_GROUP, nxt)   /* the next segment's columns are requested between the half-blocks */         \
+      BL_PASS(cur, 0, BL_CALC, BL_FETCH_GROUP, nxt)   /* the next segment's columns are requested between the half-blocks */\
       if (prof) tPass += clock64() - tp0;                                                                                   \
       unsigned long long exm = 0ull;                                  /* moves redone exactly (they wrote their own z) */   \
       if (Fb == 0u) {                                                                                                       \
@@ -2138,7 +2204,6 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
         const long long ts0 = prof ? clock64() : 0;                                                                         \
         const double (&cur_)[64] = cur;                                                                                     \
         int start = 0;                                                                                                      \
-        bool dirty = false;            /* a move was redone since the last cheap pass: its verdicts behind that move are void */ \
         for (;;) {                                                                                                          \
           if (Fb == 0u) {                                                                                                   \
             bj = bs;                                                                                                        \
@@ -2150,6 +2215,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
           double bb;                                                                                                        \
           ExactIn xin;                                                                                                      \
           if (prof) ++ncareful;                                                                                             \
+          double l8[8], bs0;                                                                                                \
           switch (Hf) {                                                                                                     \
             case 0: BL_HALF(0, bj) break;                                                                                   \
             case 1: BL_HALF(1, cp1) break;                                                                                  \
@@ -2160,27 +2226,34 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
             case 6: BL_HALF(6, cp6) break;                                                                                  \
             default: BL_HALF(7, cp7) break;                                                                                 \
           }                                                                                                                 \
+          f = run_half(l8, Hf, bs0, lastrow, lane, wave, start, mcnt, zw, x1, par, RkSeg, g4, bb, xin);                     \
           bj = bb;                                                                                                          \
-          if (f != 0u) {                           /* the first move that needs its bounds */                               \
-            const int mf = 8 * Hf + __builtin_ctz(f);                                                                       \
-            run_exact(xin, mf, cq, z1q, lane, wave, NQ, bj, sz, xl, par);                                                   \
-            exm |= 1ull << mf;                                                                                              \
-            nslow = __builtin_amdgcn_readfirstlane(nslow + 1);                                                              \
-            dirty = true;                                                                                                   \
-            start = mf + 1;                                                                                                 \
-            if (start < bend) {                    /* the rest of the half-block: the tests again, behind the move */       \
-              if (lane >= 8 * Hf && lane <= mf) zw[2 * lane] = 0.0;                                                         \
-              WAVE_SYNC();                                                                                                  \
-              continue;                                                                                                     \
-            }                                                                                                               \
+          if (f == 0u) {                           /* the chain is as the cheap pass had it: its other verdicts stand */    \
+            start = bend;                                                                                                   \
+            Fb &= ~(1u << Hf);                                                                                              \
+            if (start >= mcnt) break;              /* that was the segment's last half-block: bj is the chain's end */      \
+            continue;                                                                                                       \
           }                                                                                                                 \
-          start = bend;                                                                                                     \
-          Fb &= ~(1u << Hf);                                                                                                \
-          if (start >= mcnt) break;                /* that was the segment's last half-block: bj is the chain's end */      \
-          if (!dirty) continue;                    /* the chain is as the cheap pass had it: its other verdicts stand */    \
+          const int nf = __builtin_ctz(f), mf = 8 * Hf + nf;     /* the first move that needs its bounds */                 \
+          const long long te0 = prof ? clock64() : 0;                                                                       \
+          run_exact(xin, mf, cq, z1q, lastrow, lane, wave, NQ, bj, sz, xl, par);                                            \
+          if (prof) tExact += clock64() - te0;                                                                              \
+          exm |= 1ull << mf;                                                                                                \
+          nslow = __builtin_amdgcn_readfirstlane(nslow + 1);                                                                \
+          start = mf + 1;                                                                                                   \
+          if (start >= mcnt) break;                                                                                         \
+          /* everything behind the move again, from its chain value, in one cheap pass: the moves done retire (dz = z_c = 0, nothing */\
+          /* to test), the others are tested as ever */                                                                     \
+          {                                                                                                                 \
+            const bool inr = lane >= start && lane < mcnt;                                                                  \
+            zk[lane] = inr ? 2.51 : 0.0;                                                                                    \
+            if (!inr) *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(0.0, 0.0);                                  \
+            WAVE_SYNC();                                                                                                    \
+          }                                                                                                                 \
           if (prof) ++nrepass;                                                                                              \
-          BL_PASS(cur, Hf + 1, BL_NOFETCH, nxt)    /* the half-blocks behind the redone move again, from its chain value */ \
-          dirty = false;                                                                                                    \
+          const long long tr0 = prof ? clock64() : 0;                                                                       \
+          BL_PASS(cur, Hf, BL_CALC_K, BL_NOFETCH, nxt)                                                                      \
+          if (prof) tRepass += clock64() - tr0;                                                                             \
         }                                                                                                                   \
         if (prof) tSlow += clock64() - ts0;                                                                                 \
       }                                                                                                                     \
@@ -2199,6 +2272,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     BL_SEGMENT(colA, colB, g, k, q)
     if (++q == nseg) {
       q = 0;
+      noff += 3 * nslow >= P ? 1 : 0;
       spec_on = __builtin_amdgcn_readfirstlane((3 * nslow < P || ((k + 1) & 7) == 0) ? 1 : 0);   // a chain pressed against its bounds: every move exactly; look again every 8th scan
       nexact += (unsigned long long)nslow;
       nslow = 0;
@@ -2209,6 +2283,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
       BL_SEGMENT(colB, colA, g + 1, k, q)
       if (++q == nseg) {
         q = 0;
+        noff += 3 * nslow >= P ? 1 : 0;
         spec_on = __builtin_amdgcn_readfirstlane((3 * nslow < P || ((k + 1) & 7) == 0) ? 1 : 0);
         nexact += (unsigned long long)nslow;
         nslow = 0;
@@ -2218,18 +2293,22 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     }
   }
   if (j < P) a.beta_out[j] = bj;
+  if (t == 0) mode[1] = (2 * noff > P) ? 1u : 0u;     // most scans pressed against the bounds: the next draw goes to k_beta_sweeps
   if (prof && t == 0) {
     a.dbg[8] += nexact;
     a.dbg[12] += ncareful;
     a.dbg[13] += nrepass;
     a.dbg[19] = (unsigned long long)(clock64() - tAll);
     a.dbg[16] = 0ull;
+    a.dbg[20] = (unsigned long long)tExact;
+    a.dbg[21] = (unsigned long long)tRepass;
     a.dbg[17] = (unsigned long long)tPass;
     a.dbg[18] = (unsigned long long)tSlow;
   }
 #undef BL_SEGMENT
 #undef BL_HALF
 #undef BL_PASS
+#undef BL_CALC_K
 #undef BL_CALC
 #undef BL_NOFETCH
 #undef BL_FETCH_ALL
@@ -2248,7 +2327,7 @@ size_t beta_work_doubles(int P)
   size_t generic = 2 * (size_t)P * P + 6 * (size_t)P + 64;
   if (P > 64 && P <= 256)    // constrained_sweeps_wide: tnorm records + swap targets after the dense stage's matrices
     generic += (size_t)P * P * kRec + ((size_t)P * P + 1) / 2 + (size_t)P * P +   // + the second reciprocal matrix
-               ((size_t)P * P + 128 + 1) / 2;                                     // + the scan tables (u32, 128 entries of slack)
+               ((size_t)P * P + 128 + 1) / 2 + 2;                                 // + the scan tables (u32, 128 entries of slack) + the mode words
   const size_t small = (size_t)P * P * kRec + 2 * (((size_t)P * P + 1) / 2) + 64;   // tnorm records + int tables
   return generic > small ? generic : small;
 }
@@ -2295,10 +2374,21 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   hipLaunchKernelGGL(k_beta_finish, dim3(1), dim3(kDenseThreads), lds, s, a, mode);
   if (wide) lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;   // the one-wavefront sweeps' LDS
   if (wide && beta_split_mode() == 2) {
-    const size_t l2 = ((((size_t)a.P + 1) & ~(size_t)1) + 16 + 16 + 4 + 512) * 8;
+    const size_t l2 = ((((size_t)a.P + 1) & ~(size_t)1) + 16 + 16 + 4 + 512 + 256) * 8;
     const int nq = (a.P + 63) / 64;
     auto fn = nq == 2 ? k_beta_sweeps_run<2> : nq == 3 ? k_beta_sweeps_run<3> : k_beta_sweeps_run<4>;
     hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), l2, s, a);
+    // and behind it the one-wavefront sweeps, which take the draw instead when the chain is pressed against its bounds (one
+    // of the two returns at once: see beta_mode_word)
+    if (a.P <= 128) {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<2>, dim3(1), dim3(kBlock), lds, s, a, true);
+    } else {
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_beta_sweeps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a, true);
+    }
   } else if (wide && beta_split_mode() == 1) {
     const size_t l2 = ((size_t)a.P + 32 + 128 + 4) * 8 + (size_t)a.P * a.P;
     const int nq = (a.P + 63) / 64;
@@ -2309,11 +2399,11 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
     if (a.P <= 128) {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_beta_sweeps<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_beta_sweeps<2>, dim3(1), dim3(kBlock), lds, s, a);
+      hipLaunchKernelGGL(k_beta_sweeps<2>, dim3(1), dim3(kBlock), lds, s, a, false);
     } else {
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_beta_sweeps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a);
+      hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a, false);
     }
   }
 }
