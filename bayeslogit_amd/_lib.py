@@ -34,6 +34,7 @@ SIGNATURES = {
     "bl_set_device_R": (None, [c_ip, c_ip]),
     "bl_set_sweep_mode": (None, [C.c_int]),
     "bl_diag_sweep_deferred": (C.c_int, [C.POINTER(c_u64)]),
+    "bl_diag_beta_sweeps": (None, [C.c_int]),
     "rpg_gamma": (None, [c_dp, c_dp, c_dp, c_ip, c_ip]),
     "rpg_devroye": (None, [c_dp, c_ip, c_dp, c_ip]),
     "rpg_alt": (None, [c_dp, c_dp, c_dp, c_ip]),

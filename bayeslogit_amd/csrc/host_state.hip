@@ -23,6 +23,12 @@ int initial_sweep_mode()
   if (const char* s = getenv("BL_SWEEP_SINGLE_PASS")) return atoi(s) ? 1 : 0;
   return 1;
 }
+static int initial_beta_sweeps()
+{
+  const char* e = getenv("BL_BETA_SPLIT");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+}
+std::atomic<int> g_beta_sweeps{initial_beta_sweeps()};
 std::atomic<int> g_sweep_mode{initial_sweep_mode()};
 unsigned long long* g_sweep_stats_dev = nullptr;     // [0] rows that left the single-pass sweep's fast path
 int* g_status_dev = nullptr;
@@ -95,6 +101,7 @@ uint64_t global_seed() { return g_seed.load(); }
 uint32_t next_epoch() { return g_epoch.fetch_add(1); }
 int global_constrain() { return g_constrain.load(); }
 int sweep_single_pass() { return g_sweep_mode.load(); }
+int beta_sweeps_kind() { return g_beta_sweeps.load(); }
 unsigned long long* sweep_stats() { return g_sweep_stats_dev; }
 
 }  // namespace blh
@@ -150,6 +157,7 @@ uint32_t bl_get_epoch(void) { return g_epoch.load(); }
 void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
 void bl_set_constrain_R(int* c) { g_constrain = (c && *c) ? 1 : 0; }
 void bl_set_sweep_mode(int single_pass) { g_sweep_mode = single_pass ? 1 : 0; }
+void bl_diag_beta_sweeps(int kind) { g_beta_sweeps = (kind >= 0 && kind <= 2) ? kind : 2; }
 int bl_diag_sweep_deferred(uint64_t* rows)
 {
   if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;

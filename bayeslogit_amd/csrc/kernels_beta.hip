@@ -6,6 +6,7 @@
 // (erfc / inverse normal CDF of the tnorm fallback) otherwise park ~100 hoisted constants in registers and spill
 // SGPRs through v_writelane in the move loops.
 #include "bl_gibbs_kernels.hpp"
+#include "bl_host.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_queue.hpp"
 #include "../../include/bayeslogit_hip.h"
@@ -2332,13 +2333,10 @@ size_t beta_work_doubles(int P)
   return generic > small ? generic : small;
 }
 
-// BL_BETA_SPLIT=0: the one-wavefront sweeps (k_beta_sweeps); =1: the row-split sweeps in blocks of 16 (k_beta_sweeps_split);
-// default: the row-split sweeps in segments of 64 (k_beta_sweeps_run).  For comparison: all three give the same beta.
-static int beta_split_mode()
-{
-  static const int m = [] { const char* e = getenv("BL_BETA_SPLIT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
-  return m;
-}
+// bl_diag_beta_sweeps / BL_BETA_SPLIT: 0 = the one-wavefront sweeps (k_beta_sweeps), 1 = the row-split sweeps in blocks of
+// 16 (k_beta_sweeps_split), 2 (default) = the row-split sweeps in segments of 64 (k_beta_sweeps_run) with the
+// one-wavefront ones behind them for a pressed chain.  For comparison: all three give the same beta.
+static int beta_split_mode() { return blh::beta_sweeps_kind(); }
 
 void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
 {

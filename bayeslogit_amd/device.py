@@ -118,6 +118,11 @@ def set_sweep_mode(single_pass=True):
     _lib.lib().bl_set_sweep_mode(1 if single_pass else 0)
 
 
+def set_beta_sweeps(kind=2):
+    """Which of the three (bit-identical) kernels runs the constrained sweeps of 64 < P <= 256 (bl_diag_beta_sweeps)."""
+    _lib.lib().bl_diag_beta_sweeps(int(kind))
+
+
 def sweep_deferred_rows():
     """Rows the single-pass sweep handed to the full sampler since the last call (synchronises the device)."""
     v = C.c_uint64(0)

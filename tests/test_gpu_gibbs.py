@@ -714,3 +714,44 @@ def test_call_sequence_streams_are_separate(gpu, oracle):
     # and the chain is the oracle's chain under the derived key
     _, bo = oracle.gibbs(y, X, n, np.zeros(8), np.eye(8), 3, 1, oracle.chain_key(777, 0), 1)
     assert np.allclose(out["beta"], bo, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("P", [70, 128, 200, 256])
+def test_constrained_sweeps_three_kernels_same_bits(gpu, P):
+    """The coordinate sweeps of the constrained draw for 64 < P <= 256 (Logit.hpp:368-399) exist as three kernels --
+    rows split over four wavefronts in speculative segments of 64 moves (the default, which hands a chain that is pressed
+    against its bounds to the third), the same in blocks of 16, all rows on one wavefront: the same beta, bit for bit,
+    on a posterior with slack constraints (data-rich: almost every move takes its first normal) and on one pressed
+    against them (most moves need their bounds; the default kernel's hand-over happens inside the six draws)."""
+    from bayeslogit_amd import device as D
+    rng = np.random.default_rng(900 + P)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
+    X, y, n = synth(8, P, 1)
+    problems = [_beta_problem(P, 100 + P)]
+    Xr, yr, nr = synth(4000 * P if P <= 128 else 1500 * P, P, 7, nmax=1)
+    bt = np.abs(rng.normal(size=P)) * 0.4 + 0.3
+    yr = (rng.random(Xr.shape[0]) < 1.0 / (1.0 + np.exp(-(Xr @ bt)))).astype(np.float64)
+    w = rng.gamma(2.0, 0.12, Xr.shape[0])
+    problems.append(((Xr * w[:, None]).T @ Xr, np.eye(P) * 0.01, Xr.T @ (yr - 0.5), bt.copy()))
+    try:
+        for PPsum, P0, bP, bprev in problems:
+            out = {}
+            for kind in (2, 1, 0):
+                D.set_beta_sweeps(kind)
+                g = shard_of(X, y, n, gpu, seed=4321)
+                g.set_prior(np.zeros(P), P0)
+                draws = []
+                for s in range(6):
+                    g.pp().copy_(t(np.asfortranarray(PPsum).ravel(order="F")))
+                    g.bp().copy_(t(bP))
+                    if s == 0:
+                        g.beta().copy_(t(bprev))
+                    g.draw_beta(s, 1)
+                    draws.append(g.beta().cpu().numpy().copy())
+                D.sync_status()
+                g.close()
+                out[kind] = np.stack(draws)
+                assert np.all(np.isfinite(out[kind])) and np.all(out[kind][:, :-1] >= 0.0)
+            assert np.array_equal(out[2], out[1]) and np.array_equal(out[2], out[0])
+    finally:
+        D.set_beta_sweeps(2)
