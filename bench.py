@@ -360,12 +360,13 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         tri = nbk * (nbk + 1) // 2
         flops = 2.0 * nl * tri * 256                       # upper-triangle 16x16 blocks of the rank-N update
         tf = flops / (sk * 1e-3) / 1e12
-        xk = f"k_xwx_q4_big<{nbk}> + k_reduce_q4_big<{nbk}>" if P in (128, 256) else f"k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>"
+        xk = ("k_xwx_q4_blk16 + k_reduce_q4_blk16" if P == 256 else "k_xwx_q4_big<8> + k_reduce_q4_big<8>" if P == 128
+              else f"k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>")
         roof = {"kernel": f"k_psi_omega_nb<{nbk},0> + " + xk, "bound": "mfma",
                 "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": None, "algorithmic_flops_per_launch": flops,
                 "note": "whole sweep time (both passes) against the fp64 MFMA peak; X' Omega X alone is "
-                        "k_xwx_q4_big in profiles/"}
+                        "k_xwx_q4_blk16 (P = 256) / k_xwx_q4_big<8> (P = 128) in profiles/"}
     roof["kernel_ms"] = sk
     # the fp64 matrix pipe as measured on this GPU (register-only MFMA loop, 2 waves/SIMD): the X'Omega X pass
     # cannot take less than its flops at that rate

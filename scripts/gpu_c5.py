@@ -7,7 +7,7 @@ from bayeslogit_amd import device as D
 sys.argv=['x']
 import bench
 dev=torch.device('cuda:0')
-N,P=int(os.environ.get('BL_N','4000000')),256
+N,P=int(os.environ.get('BL_N','4000000')),int(os.environ.get('BL_P','256'))
 X,y,bt=bench.synth_logit(D,dev,N,P)
 nn=torch.ones(N,dtype=torch.float64,device=dev)
 sh=D.GibbsShard(X,y,nn,seed=20240004)
