@@ -2011,11 +2011,18 @@ __global__ __launch_bounds__(1024) void k_beta_scan_tables(blk::BetaArgs a)
     }
   }
   __syncthreads();
+  const int k0 = t / P, kstep = nthr / P, istep = nthr - kstep * P;      // e = k P + i walks by nthr without a division
   for (int d = 1; d < P; d <<= 1) {
+    int k = k0, i = t - k0 * P;
     for (int e = t; e < P * P; e += nthr) {
-      const int k = e / P;
       const unsigned char v = A[e];
       Bf[e] = k >= d ? A[(k - d) * P + v] : v;
+      k += kstep;
+      i += istep;
+      if (i >= P) {
+        i -= P;
+        ++k;
+      }
     }
     __syncthreads();
     unsigned char* tmp = A;
