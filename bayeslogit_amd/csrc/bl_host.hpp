@@ -25,7 +25,7 @@ uint64_t global_seed();
 uint32_t next_epoch();                      // returns current, then increments
 int      global_constrain();
 int      sweep_single_pass();               // bl_set_sweep_mode / BL_SWEEP_SINGLE_PASS (default 1)
-int      beta_sweeps_kind();                // bl_diag_beta_sweeps / BL_BETA_SPLIT (default 2)
+int      beta_sweeps_kind();                // bl_diag_beta_sweeps / BL_BETA_SPLIT (default 1: row-split sweeps)
 unsigned long long* sweep_stats();          // device counters of the single-pass sweep (bl_diag_sweep_deferred)
 
 #define BL_HIP_TRY(expr)                                                            \

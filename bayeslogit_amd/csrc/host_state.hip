@@ -26,7 +26,7 @@ int initial_sweep_mode()
 static int initial_beta_sweeps()
 {
   const char* e = getenv("BL_BETA_SPLIT");
-  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2;
+  return (e && e[0] == '0') ? 0 : 1;
 }
 std::atomic<int> g_beta_sweeps{initial_beta_sweeps()};
 std::atomic<int> g_sweep_mode{initial_sweep_mode()};
@@ -157,7 +157,7 @@ uint32_t bl_get_epoch(void) { return g_epoch.load(); }
 void bl_set_constrain(int c) { g_constrain = c ? 1 : 0; }
 void bl_set_constrain_R(int* c) { g_constrain = (c && *c) ? 1 : 0; }
 void bl_set_sweep_mode(int single_pass) { g_sweep_mode = single_pass ? 1 : 0; }
-void bl_diag_beta_sweeps(int kind) { g_beta_sweeps = (kind >= 0 && kind <= 2) ? kind : 2; }
+void bl_diag_beta_sweeps(int row_split) { g_beta_sweeps = row_split ? 1 : 0; }
 int bl_diag_sweep_deferred(uint64_t* rows)
 {
   if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;

@@ -1499,23 +1499,9 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
 }
 
 // ---- the same sweeps with the ROWS split over the wavefronts: wave w owns rows 64 w + lane (one row per lane, beta_j in
-// a register).  A scan is NQ = ceil(P / 64) segments of 64 moves; at the start of a segment a lane loads its row's
-// entry of the 64 columns of L the segment will visit (one L2 latency per segment, 128 registers), and the moves
-// are taken in speculative blocks of 16 (k_beta64's scheme): assuming every move of the block takes its first
-// Box-Muller normal s (z' = s, dz = s - z_c: known up front, because a scan visits every coordinate once), each
-// wavefront walks the block on its own rows and the wavefronts meet once per block (three 16-bit masks through LDS,
-// one barrier).
-//
-// The sufficient tests of k_beta64 -- lo <= min(s, -a), hi >= max(s, b) for (a, b) in {(1.26, 1.26), (0, 2.51),
-// (2.51, 0)} -- are run here without the bounds: "lo <= p <= hi" says that z' = p keeps every constrained row
-// non-negative, beta_j + L_jc (p - z_c) >= 0 (Logit.hpp:383-391 are exactly these inequalities solved for z'), so a
-// test passes iff the rows are feasible at s, at -a and at b: six FMAs per row and move (s and the five points
-// -2.51, -1.26, 0, 1.26, 2.51), sign bits OR-ed, one ballot per test; no reciprocals, no NaN masks, one load per
-// row and move instead of three.  A block with no failing move commits.  Otherwise the moves before the first
-// failing one commit, beta_j is rolled back to that point, that one move is redone with its exact bounds
-// (split_exact: reciprocal columns, DPP max/min per wavefront, four results through LDS, the tnorm record's attempts
-// evaluated redundantly by every wavefront) and the block resumes behind it.  Same decisions as the one-wavefront
-// kernel up to the rounding of the tests' left-hand sides; same arithmetic for beta_j.
+// a register); k_beta_sweeps_run below.  split_exact is one move taken with its exact bounds by the four wavefronts
+// together (reciprocal columns, DPP max/min per wavefront, four results through LDS, the tnorm record's attempts evaluated
+// redundantly by every wavefront): what a scan of a chain pressed against its bounds runs move by move.
 __device__ __forceinline__ void split_exact(const double* __restrict__ Lg, const double* __restrict__ Rg,
                                             const double* __restrict__ Rh, const double* __restrict__ RkSeg, int P, int jr,
                                             int lane, int wave, int nq, int i, int cq, double z1q, double& bj, double* sz,
@@ -1546,299 +1532,25 @@ __device__ __forceinline__ void split_exact(const double* __restrict__ Lg, const
   if (wave == 0 && lane == 0) sz[c] = z2;
 }
 
-// Moves [max(ustart, 16 B), min(uend, 16 B + 16)) of the segment, speculatively.  Returns the index of the first move
-// not done: uend's clamp if the block passed, else (negated) one past the move that was redone exactly.
-template <int B>
-__device__ __forceinline__ int split_block(const double (&l1seg)[64], const double* __restrict__ Lg,
-                                           const double* __restrict__ Rg, const double* __restrict__ Rh,
-                                           const double* __restrict__ RkSeg, int P, int jr, bool lastrow, int lane,
-                                           int wave, int nq, int ustart, int uend, int cq, double sq, double z1q,
-                                           double dzq, double& bj, double* sz, uint32_t* xm, double* xl, unsigned& par,
-                                           int g4, double* zdw, uint32_t* x1, long long (&tim)[4], bool prof)
-{
-  // straight-line over the block's 16 moves (the compiler interleaves the moves' independent test arithmetic; only
-  // beta_j's running value chains them).  Moves outside [ustart, uend) get dz = 0 and their test bits are masked off.
-  // A lane keeps its rows' verdicts as bits (no ballot per move: 48 ballots a block and their scalar bookkeeping cost
-  // more than the tests); the lanes' bits meet in one DPP OR-reduction per block.
-  const double dzm = (lane >= ustart && lane < uend) ? dzq : 0.0;
-  const int lo_m = ustart > 16 * B ? ustart : 16 * B, hi_m = uend < 16 * B + 16 ? uend : 16 * B + 16;
-  const uint32_t valid = ((hi_m - 16 * B) >= 16 ? 0xFFFFu : ((1u << (hi_m - 16 * B)) - 1u)) & ~((1u << (lo_m - 16 * B)) - 1u);
-  // First the cheap test: the whole of [-2.51, 2.51] and s feasible for every row (beta_j - L z_c - 2.51 |L| >= 0 covers
-  // both ends at once; beta_j after the move is the value the chain needs anyway), which implies test (1.26, 1.26).
-  // Three FMAs and an OR per row and move, one verdict for the block (a block that fails goes to the tests below, which
-  // locate the move); z_c and dz come back from LDS as wave-uniform vector operands (broadcast reads, all in flight
-  // together) instead of four v_readlane per move.  ~99 % of the moves of a settled chain pass.
-  {
-    const long long q0 = prof ? clock64() : 0;
-    if ((lane >> 4) == B) {
-      zdw[2 * (lane & 15)] = (lane >= ustart && lane < uend) ? z1q : 0.0;
-      zdw[2 * (lane & 15) + 1] = dzm;
-    }
-    double z1v[16], dzv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      z1v[u] = zdw[2 * u];
-      dzv[u] = zdw[2 * u + 1];
-    }
-    __builtin_amdgcn_sched_barrier(0);       // all sixteen reads in flight before the first use
-    if (prof) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tim[0] += clock64() - q0;
-    }
-    const long long q1 = prof ? clock64() : 0;
-    double bsv[17], gv[16];
-    bsv[0] = bj;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double l1 = l1seg[16 * B + u];
-      bsv[u + 1] = fma(l1, dzv[u], bsv[u]);
-      gv[u] = fma(-l1, z1v[u], bsv[u]);
-    }
-    uint32_t acc = 0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double wu = ((valid >> u) & 1u) ? 2.51 : 0.0;            // wave-uniform: a move outside the range tests nothing
-      const double e = fma(-wu, fabs(l1seg[16 * B + u]), gv[u]);
-      acc |= (uint32_t)__double2hiint(e) | (uint32_t)__double2hiint(bsv[u + 1]);
-    }
-    const bool bad1 = !lastrow && (acc >> 31) != 0u;
-    const uint32_t any1 = __ballot(bad1) != 0ull ? 1u : 0u;
-    if (prof) tim[1] += clock64() - q1;
-    const long long q2 = prof ? clock64() : 0;
-    uint32_t* slot1 = x1 + par * 4;
-    if (lane == 0) slot1[wave] = any1;
-    __syncthreads();
-    const uint4 sv = *reinterpret_cast<const uint4*>(slot1);
-    par ^= 1u;
-    const int anyf = __builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w));
-    if (prof) tim[2] += clock64() - q2;
-    if (anyf == 0) {
-      bj = bsv[16];
-      if (wave == 0 && lane >= lo_m && lane < hi_m) sz[cq] = sq;
-      return hi_m;
-    }
-  }
-  double bs = bj;
-  uint32_t pA = 0, pB = 0, pC = 0;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    constexpr int base = 16 * B;
-    const int m = base + u;
-    const double z1 = readlane_f64(z1q, m), dz = readlane_f64(dzm, m);
-    const double l1 = l1seg[m];
-    // a row with L(j, c) = 0 (j < c) does not move: its three values are beta_j itself, non-negative in a feasible chain
-    // (a negative one only sends the move to the exact path, which ignores such rows as Logit.hpp:384-391 does)
-    const double g = fma(-l1, z1, bs);                               // beta_j + L (p - z_c) at p = 0
-    const double es = fma(l1, dz, bs);                               //                      at p = s: beta_j after the move
-    const double e1 = fma(l1, -2.51, g), e2 = fma(l1, -1.26, g), e3 = fma(l1, 1.26, g), e4 = fma(l1, 2.51, g);
-    const uint32_t hs = (uint32_t)__double2hiint(es), h0 = (uint32_t)__double2hiint(g);
-    pA |= ((hs | (uint32_t)__double2hiint(e2) | (uint32_t)__double2hiint(e3)) >> 31) << u;   // (1.26, 1.26)
-    pB |= ((hs | h0 | (uint32_t)__double2hiint(e4)) >> 31) << u;                             // (0, 2.51)
-    pC |= ((hs | (uint32_t)__double2hiint(e1) | h0) >> 31) << u;                             // (2.51, 0)
-    bs = es;
-  }
-  if (lastrow) pA = pB = pC = 0u;                                    // row P-1 is not constrained (Logit.hpp:383: j < P-1)
-  uint32_t mA, mB, mC;
-  {
-    uint32_t ab = pA | (pB << 16), cc = pC;
-    ab = wave_or_u32(ab);
-    cc = wave_or_u32(cc);
-    mA = ab & valid;
-    mB = (ab >> 16) & valid;
-    mC = cc & valid;
-  }
-  uint32_t* slot = xm + par * 16;
-  if (lane == 0) {
-    slot[wave * 4 + 0] = mA;
-    slot[wave * 4 + 1] = mB;
-    slot[wave * 4 + 2] = mC;
-  }
-  __syncthreads();
-  uint32_t A = 0, Bm = 0, C = 0;
-  for (int w = 0; w < nq; ++w) {
-    A |= slot[w * 4 + 0];
-    Bm |= slot[w * 4 + 1];
-    C |= slot[w * 4 + 2];
-  }
-  par ^= 1u;
-  const uint32_t fail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(A & Bm & C));
-  if (fail == 0u) {
-    bj = bs;
-    if (wave == 0 && lane >= lo_m && lane < hi_m) sz[cq] = sq;
-    return hi_m;
-  }
-  const int f = __builtin_ctz(fail);
-  const int mf = 16 * B + f;
-  // the moves before mf stand; beta_j as it was just before move mf
-  double bb = bj;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int m = 16 * B + u;
-    if (m >= ustart && u < f) bb = fma(l1seg[m], readlane_f64(dzq, m), bb);
-  }
-  if (wave == 0 && lane >= lo_m && lane < mf) sz[cq] = sq;
-  bj = bb;
-  split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, nq, mf, cq, z1q, bj, sz, xl, par, g4);
-  return -(mf + 1);
-}
-
-template <int NQ>
-__global__ __launch_bounds__(kBlock) void k_beta_sweeps_split(blk::BetaArgs a)
-{
-  extern __shared__ double lds[];
-  if (*a.status & ST_NOT_PD) return;       // see k_beta
-  const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
-  const double* __restrict__ Rg = a.work;                          // 1/L where L > 0, else NaN (k_beta's A)
-  const double* __restrict__ Lg = a.work + (size_t)P * P;          // L     (k_beta's S)
-  const double* zz = a.work + 2 * (size_t)P * P + P;               // z
-  const double* rec = a.work + 2 * (size_t)P * P + 2 * (size_t)P;
-  const int* swp = reinterpret_cast<const int*>(rec + (size_t)P * P * kRec);
-  const double* __restrict__ Rh = rec + (size_t)P * P * kRec + ((size_t)P * P + 1) / 2;   // 1/L where L < 0, else NaN
-  double* sz = lds;                                              // z (P)
-  uint32_t* xm = reinterpret_cast<uint32_t*>(sz + P);            // [2][4 waves][4]: the blocks' test masks
-  double* xl = sz + P + 16;                                      // [2][4 waves][2]: a move's bound candidates
-  double* zdw = xl + 16 + 32 * (t >> 6);                         // [4 waves][16][2]: a block's (z_c, dz), read back wave-uniform
-  uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16 + 128);     // [2][4 waves]: the blocks' cheap-test verdicts (slots of unused waves stay 0)
-  unsigned char* ptab = reinterpret_cast<unsigned char*>(xl + 16 + 128 + 4);   // ptab[k][i]: coordinate of move i of scan k
-  for (int j = t; j < P; j += nthr) sz[j] = zz[j];
-  if (t < 8) x1[t] = 0u;
-  __syncthreads();
-  // scan permutations: each scan's swaps on the identity (thread k), then composed in scan order
-  if (t < P) {
-    unsigned char* sg = ptab + t * P;
-    for (int i = 0; i < P; ++i) sg[i] = (unsigned char)i;
-    for (int i = 0; i < P - 1; ++i) {
-      const int j = swp[t * (P - 1) + i];
-      const unsigned char tmp = sg[i];
-      sg[i] = sg[j];
-      sg[j] = tmp;
-    }
-  }
-  __syncthreads();
-  for (int k = 1; k < P; ++k) {
-    int v = 0;
-    if (t < P) v = ptab[(k - 1) * P + ptab[k * P + t]];
-    __syncthreads();
-    if (t < P) ptab[k * P + t] = (unsigned char)v;
-    __syncthreads();
-  }
-
-  const int lane = t & 63, wave = t >> 6;
-  const int j = 64 * wave + lane;
-  const int jr = j < P ? j : P - 1;          // a lane past the matrix rides on row P-1, which no test looks at
-  const bool lastrow = jr == P - 1;
-  double bj = j < P ? a.beta_prev[j] : 0.0;
-  const int g4 = (lane < 5 ? lane : 0) * 4;
-  unsigned par = 0;
-  bool spec_on = true;
-  // a lane's entries of the 64 columns of L a segment visits, fetched one segment ahead (the tables of every scan exist)
-#define BL_FETCH_SEG(dst, kk, qq)                                                                        \
-  {                                                                                                      \
-    const int m0n = 64 * (qq);                                                                           \
-    const bool hasn = lane < P - m0n;                                                                    \
-    cq_n = hasn ? (int)ptab[(kk) * P + m0n + lane] : 0;                                                  \
-    sq_n = hasn ? rec[((size_t)(kk) * P + m0n + lane) * kRec + 3] : 0.0;                                 \
-    _Pragma("unroll") for (int u = 0; u < 64; ++u) dst[u] = Lg[(size_t)__builtin_amdgcn_readlane(cq_n, u) * P + jr]; \
-  }
-  double l1nxt[64];
-  int cq_n;             // lane i: coordinate of move i of the next segment
-  double sq_n;          //         its first Box-Muller normal
-  BL_FETCH_SEG(l1nxt, 0, 0)
-  const bool prof = a.dbg != nullptr;
-  long long cSeg = 0, cOk = 0, cFail = 0, cPre = prof ? clock64() : 0;
-  long long tim[4] = {0, 0, 0, 0};
-  for (int k = 0; k < P; ++k) {
-    const unsigned char* pk = ptab + k * P;
-    int nslow = 0, nblocks = 0;
-#pragma unroll 1
-    for (int q = 0; q < NQ; ++q) {
-      const int m0 = 64 * q;
-      const int mcnt = (P - m0) < 64 ? (P - m0) : 64;
-      if (mcnt <= 0) break;
-      const double* RkSeg = rec + ((size_t)k * P + m0) * kRec;
-      const bool has = lane < mcnt;
-      const long long ts0 = prof ? clock64() : 0;
-      const int cq = cq_n;                                              // lane i: coordinate of move m0 + i
-      const double sq = sq_n;                                           //         its first Box-Muller normal
-      const double z1q = has ? sz[cq] : 0.0;                            //         z_c before the move (a scan visits c once)
-      const double dzq = sq - z1q;
-      double l1seg[64];
-#pragma unroll
-      for (int u = 0; u < 64; ++u) l1seg[u] = l1nxt[u];
-      {
-        int qn = q + 1, kn = k;
-        if (64 * qn >= P) {
-          qn = 0;
-          kn = k + 1;
-        }
-        if (kn < P) BL_FETCH_SEG(l1nxt, kn, qn)
-      }
-      if (!spec_on) {                                                    // a chain pressed against its bounds: every move exactly
-        for (int i = 0; i < mcnt; ++i)
-          split_exact(Lg, Rg, Rh, RkSeg, P, jr, lane, wave, NQ, i, cq, z1q, bj, sz, xl, par, g4);
-        nslow += mcnt;
-        continue;
-      }
-      int i0 = 0;
-      if (prof) cSeg += clock64() - ts0;
-      while (i0 < mcnt) {
-        int r;
-        const long long tb0 = prof ? clock64() : 0;
-        if (i0 < 16)
-          r = split_block<0>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
-        else if (i0 < 32)
-          r = split_block<1>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
-        else if (i0 < 48)
-          r = split_block<2>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
-        else
-          r = split_block<3>(l1seg, Lg, Rg, Rh, RkSeg, P, jr, lastrow, lane, wave, NQ, i0, mcnt, cq, sq, z1q, dzq, bj, sz, xm, xl, par, g4, zdw, x1, tim, prof);
-        if (prof) {
-          if (r < 0) cFail += clock64() - tb0;
-          else cOk += clock64() - tb0;
-        }
-        if (r < 0) {
-          ++nslow;
-          r = -r;
-        }
-        ++nblocks;
-        i0 = r;
-      }
-    }
-    // a chain pressed against its bounds fails most blocks: stop speculating, look again every 8th scan
-    spec_on = 3 * nslow < P || ((k + 1) & 7) == 0;
-    if (a.dbg && t == 0) {
-      a.dbg[8] += (unsigned long long)nslow;
-      a.dbg[12] += (unsigned long long)nblocks;
-    }
-    __syncthreads();         // the scan's z are in LDS before the next scan gathers them
-  }
-  if (j < P) a.beta_out[j] = bj;
-  if (prof && t == 0) {
-    a.dbg[16] = (unsigned long long)cSeg;
-    a.dbg[17] = (unsigned long long)cOk;
-    a.dbg[18] = (unsigned long long)cFail;
-    a.dbg[19] = (unsigned long long)(clock64() - cPre);
-    a.dbg[20] = (unsigned long long)tim[0];
-    a.dbg[21] = (unsigned long long)tim[1];
-    a.dbg[22] = (unsigned long long)tim[2];
-  }
-#undef BL_FETCH_SEG
-}
-
-// ---- the row-split sweeps again, with the speculative unit a whole SEGMENT of 64 moves (k_beta_sweeps_split: blocks of 16,
-// one barrier each) and little but the dependent chain left in it:
+// ---- the row-split sweeps: the P^2 moves of a draw in speculative SEGMENTS of 64 (assuming every move takes its first
+// Box-Muller normal s, dz = s - z_c is known for the whole segment up front, because a scan visits every coordinate once:
+// each wavefront walks the segment on its own rows and the four meet once per segment), with little but the dependent chain
+// left in the walk:
 //   * the scan tables (the coordinate of move i of scan k) come from k_beta_scan_tables in global memory; a lane holds the
 //     column offsets of the segment after next (loaded two segments ahead), so fetching a move's column of L is one
 //     v_readlane and one buffer load (row offset in a register, column offset as the scalar offset);
 //   * the two column sets (this segment's, the next one's) swap roles from segment to segment: no register copies;
-//   * the cheap test (k_beta_sweeps_split's: the whole of [-2.51, 2.51] and s feasible for the row, three FMAs and an OR
+//   * the cheap test (the whole of [-2.51, 2.51] and s feasible for the row -- beta_j - L z_c - 2.51 |L| >= 0 covers both ends
+//     at once, and beta_j after the move is the value the chain needs anyway -- which implies k_beta64's test (1.26, 1.26),
+//     hence tnorm's first branch with s inside: three FMAs and an OR
 //     per row and move) runs on whole blocks of 16 with the sign bits OR-ed per block; (dz, z_c) reach the wave as uniform
 //     operands through the wave's own LDS slot (broadcast reads, half a block ahead of the arithmetic); the four
 //     wavefronts meet once per segment (one word each);
-//   * a block that fails (or is cut by the end of the scan) runs k_beta_sweeps_split's three tests from the chain value
+//   * a half-block that fails (or is cut by the end of the scan) runs k_beta64's three sufficient tests in their
+//     feasibility form (beta_j + L_jc (p - z_c) >= 0 at p in {s, +-1.26, 0, +-2.51}: no reciprocals) from the chain value
 //     the cheap pass left at its start; a move that fails those is redone with its exact bounds (split_exact), the rest of
 //     its block goes through the three tests again and the blocks behind it through a new cheap pass.
-// Same decisions as k_beta_sweeps_split up to the rounding of the tests' left-hand sides; same arithmetic for beta_j.
+// Same decisions as the one-wavefront kernel up to the rounding of the tests' left-hand sides; same arithmetic for beta_j.
 template <int H>      // H: half-block of 8 moves
 __device__ __forceinline__ void run_load(const double* zw, double (&dz)[8], double (&z1)[8])
 {
@@ -1897,7 +1609,7 @@ struct ExactIn {
 };
 
 // Half-block H (moves 8 H .. 8 H + 7; its entries of L copied to l8: one body of code for the eight, the path is rare and
-// its code cold) of a segment the slow way: k_beta_sweeps_split's three sufficient tests from the
+// its code cold) of a segment the slow way: the three sufficient tests from the
 // chain value bs at its start (a move before `start` carries dz = 0 in the wave's LDS slot and is not tested).  Returns the
 // mask of the moves that fail all three somewhere in the matrix (wave-uniform, the same in every wave) and, in bb, the
 // chain value just before the first of them (after the half-block if there is none); for that move the exact path's
@@ -2051,9 +1763,8 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int Pe = (P + 1) & ~1;                                   // 16-byte alignment of what follows
   double* sz = lds;                                              // z (P)
-  uint32_t* xm = reinterpret_cast<uint32_t*>(sz + Pe);           // [2][4 waves][4]: a block's three test masks
-  double* xl = sz + Pe + 16;                                     // [2][4 waves][2]: a move's bound candidates
-  uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16);           // [2][4 waves]: a segment's cheap verdicts
+  double* xl = sz + Pe + 16;                                     // [2][4 waves][2]: a move's bound candidates (16 doubles before it: spare)
+  uint32_t* x1 = reinterpret_cast<uint32_t*>(xl + 16);           // [2][4 waves]: a pass's verdicts / a half-block's three test masks
   double* zw = xl + 16 + 4 + 128 * wave;                         // [4 waves][64][2]: the wave's (dz, z_c), read back uniform
   double* zk = xl + 16 + 4 + 512 + 64 * wave;                    // [4 waves][64]: the test's half-width per move (a pass taken again)
   for (int j = t; j < P; j += nthr) sz[j] = zz[j];
@@ -2340,10 +2051,10 @@ size_t beta_work_doubles(int P)
   return generic > small ? generic : small;
 }
 
-// bl_diag_beta_sweeps / BL_BETA_SPLIT: 0 = the one-wavefront sweeps (k_beta_sweeps), 1 = the row-split sweeps in blocks of
-// 16 (k_beta_sweeps_split), 2 (default) = the row-split sweeps in segments of 64 (k_beta_sweeps_run) with the
-// one-wavefront ones behind them for a pressed chain.  For comparison: all three give the same beta.
-static int beta_split_mode() { return blh::beta_sweeps_kind(); }
+// bl_diag_beta_sweeps / BL_BETA_SPLIT: 1 (default) = the row-split sweeps in segments of 64 (k_beta_sweeps_run) with the
+// one-wavefront ones (k_beta_sweeps) behind them for a pressed chain; 0 = the one-wavefront sweeps alone.  For comparison:
+// both give the same beta.
+static bool beta_row_split() { return blh::beta_sweeps_kind() != 0; }
 
 void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
 {
@@ -2359,7 +2070,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   // P > 64: factor (one workgroup) -> inverse (a workgroup per 64 columns) -> finish (one workgroup) [-> sweeps]
   const bool wide = mode == B_CONSTRAINED && a.P <= 256;
   if (wide) hipLaunchKernelGGL(k_beta_records, dim3(64), dim3(256), 0, s, a);
-  if (wide && beta_split_mode() == 2) {
+  if (wide && beta_row_split()) {
     const size_t lt = 2 * (size_t)a.P * a.P;
     if (lt > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_beta_scan_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt);
@@ -2378,7 +2089,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   }
   hipLaunchKernelGGL(k_beta_finish, dim3(1), dim3(kDenseThreads), lds, s, a, mode);
   if (wide) lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;   // the one-wavefront sweeps' LDS
-  if (wide && beta_split_mode() == 2) {
+  if (wide && beta_row_split()) {
     const size_t l2 = ((((size_t)a.P + 1) & ~(size_t)1) + 16 + 16 + 4 + 512 + 256) * 8;
     const int nq = (a.P + 63) / 64;
     auto fn = nq == 2 ? k_beta_sweeps_run<2> : nq == 3 ? k_beta_sweeps_run<3> : k_beta_sweeps_run<4>;
@@ -2394,12 +2105,6 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
         (void)hipFuncSetAttribute((const void*)k_beta_sweeps<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(k_beta_sweeps<4>, dim3(1), dim3(kBlock), lds, s, a, true);
     }
-  } else if (wide && beta_split_mode() == 1) {
-    const size_t l2 = ((size_t)a.P + 32 + 128 + 4) * 8 + (size_t)a.P * a.P;
-    const int nq = (a.P + 63) / 64;
-    auto fn = nq == 2 ? k_beta_sweeps_split<2> : nq == 3 ? k_beta_sweeps_split<3> : k_beta_sweeps_split<4>;
-    if (l2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-    hipLaunchKernelGGL(fn, dim3(1), dim3(kBlock), l2, s, a);
   } else if (wide) {
     if (a.P <= 128) {
       if (lds > 64 * 1024)

@@ -118,9 +118,9 @@ def set_sweep_mode(single_pass=True):
     _lib.lib().bl_set_sweep_mode(1 if single_pass else 0)
 
 
-def set_beta_sweeps(kind=2):
-    """Which of the three (bit-identical) kernels runs the constrained sweeps of 64 < P <= 256 (bl_diag_beta_sweeps)."""
-    _lib.lib().bl_diag_beta_sweeps(int(kind))
+def set_beta_sweeps(row_split=True):
+    """Which of the two (bit-identical) kernels runs the constrained sweeps of 64 < P <= 256 (bl_diag_beta_sweeps)."""
+    _lib.lib().bl_diag_beta_sweeps(1 if row_split else 0)
 
 
 def sweep_deferred_rows():

@@ -141,11 +141,11 @@ int bl_diag_mfma_f64_small_dev(double *work, int64_t work_doubles, int waves_per
  * bl_diag_sweep_deferred: rows the single-pass kernel handed to the full sampler since the last call (a sync). */
 void bl_set_sweep_mode(int single_pass);
 int  bl_diag_sweep_deferred(uint64_t *rows);
-/* The coordinate sweeps of the constrained beta draw (Logit.hpp:368-399) for 64 < P <= 256 exist three times, for
- * comparison: kind 2 (default; env BL_BETA_SPLIT) = rows split over four wavefronts, speculative segments of 64 moves,
- * with a chain that is pressed against its bounds handed to kind 0 by itself; 1 = the same in blocks of 16; 0 = all rows
- * on one wavefront.  Same beta bit for bit. */
-void bl_diag_beta_sweeps(int kind);
+/* The coordinate sweeps of the constrained beta draw (Logit.hpp:368-399) for 64 < P <= 256 exist twice, for comparison:
+ * row_split = 1 (default; env BL_BETA_SPLIT) = rows split over four wavefronts, speculative segments of 64 moves, with a
+ * chain that is pressed against its bounds handed to the other kernel by itself; 0 = all rows on one wavefront, move by
+ * move.  Same beta bit for bit. */
+void bl_diag_beta_sweeps(int row_split);
 /* y[i] ~ Bernoulli(sigmoid(x_i . beta)) for a P x N column-major tX */
 int bl_fill_logit_y_dev(double *y, const double *tX, const double *beta, int64_t N, int P,
                         uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);

@@ -1,5 +1,5 @@
 """The replicated P x P stage alone (PP + P0, Cholesky, beta draw) on posteriors of the shape a chain sees.
-    python scripts/gpu_beta.py P [P ...]        (BL_BETA_SPLIT=0 / 1: the one-wavefront sweeps / the 16-move blocks for 64 < P <= 256)
+    python scripts/gpu_beta.py P [P ...]        (BL_BETA_SPLIT=0: the one-wavefront sweeps for 64 < P <= 256)
 The digest printed per line covers every bit of the six draws' beta: equal digests across BL_BETA_SPLIT settings = same chain."""
 import hashlib
 import sys

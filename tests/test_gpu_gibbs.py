@@ -717,10 +717,10 @@ def test_call_sequence_streams_are_separate(gpu, oracle):
 
 
 @pytest.mark.parametrize("P", [70, 128, 200, 256])
-def test_constrained_sweeps_three_kernels_same_bits(gpu, P):
-    """The coordinate sweeps of the constrained draw for 64 < P <= 256 (Logit.hpp:368-399) exist as three kernels --
-    rows split over four wavefronts in speculative segments of 64 moves (the default, which hands a chain that is pressed
-    against its bounds to the third), the same in blocks of 16, all rows on one wavefront: the same beta, bit for bit,
+def test_constrained_sweeps_two_kernels_same_bits(gpu, P):
+    """The coordinate sweeps of the constrained draw for 64 < P <= 256 (Logit.hpp:368-399) exist as two kernels -- rows
+    split over four wavefronts in speculative segments of 64 moves (the default, which hands a chain that is pressed
+    against its bounds to the other), all rows on one wavefront move by move: the same beta, bit for bit,
     on a posterior with slack constraints (data-rich: almost every move takes its first normal) and on one pressed
     against them (most moves need their bounds; the default kernel's hand-over happens inside the six draws)."""
     from bayeslogit_amd import device as D
@@ -736,7 +736,7 @@ def test_constrained_sweeps_three_kernels_same_bits(gpu, P):
     try:
         for PPsum, P0, bP, bprev in problems:
             out = {}
-            for kind in (2, 1, 0):
+            for kind in (1, 0):
                 D.set_beta_sweeps(kind)
                 g = shard_of(X, y, n, gpu, seed=4321)
                 g.set_prior(np.zeros(P), P0)
@@ -752,6 +752,6 @@ def test_constrained_sweeps_three_kernels_same_bits(gpu, P):
                 g.close()
                 out[kind] = np.stack(draws)
                 assert np.all(np.isfinite(out[kind])) and np.all(out[kind][:, :-1] >= 0.0)
-            assert np.array_equal(out[2], out[1]) and np.array_equal(out[2], out[0])
+            assert np.array_equal(out[1], out[0])
     finally:
-        D.set_beta_sweeps(2)
+        D.set_beta_sweeps(1)
