@@ -1540,9 +1540,9 @@ __device__ __forceinline__ void split_exact(const double* __restrict__ Lg, const
 //     column offsets of the segment after next (loaded two segments ahead), so fetching a move's column of L is one
 //     v_readlane and one buffer load (row offset in a register, column offset as the scalar offset);
 //   * the two column sets (this segment's, the next one's) swap roles from segment to segment: no register copies;
-//   * the cheap test (the whole of [-2.51, 2.51] and s feasible for the row -- beta_j - L z_c - 2.51 |L| >= 0 covers both ends
-//     at once, and beta_j after the move is the value the chain needs anyway -- which implies k_beta64's test (1.26, 1.26),
-//     hence tnorm's first branch with s inside: three FMAs and an OR
+//   * the cheap test is k_beta64's test (1.26, 1.26) in feasibility form: [-1.26, 1.26] and s feasible for the row -- beta_j -
+//     L z_c - 1.26 |L| >= 0 covers both ends at once, and beta_j after the move is the value the chain needs anyway --
+//     hence an interval wider than sqrt(2 pi) around 0 with s inside, tnorm's first branch, z' = s: three FMAs and an OR
 //     per row and move) runs on whole blocks of 16 with the sign bits OR-ed per block; (dz, z_c) reach the wave as uniform
 //     operands through the wave's own LDS slot (broadcast reads, half a block ahead of the arithmetic); the four
 //     wavefronts meet once per segment (one word each);
@@ -1569,14 +1569,14 @@ __device__ __forceinline__ void run_calc(const double (&l1)[64], const double (&
   for (int u = 0; u < 8; ++u) {
     const double l = l1[8 * H + u];
     const double g = fma(-l, z1[u], bs);        // beta_j + L (p - z_c) at p = 0
-    double e;                                   // ... at the worse end of [-2.51, 2.51] (by hand: the compiler would keep
-    asm("v_fma_f64 %0, -|%1|, %2, %3" : "=v"(e) : "v"(l), "s"(2.51), "v"(g));   // |l| of the whole segment in registers)
+    double e;                                   // ... at the worse end of [-1.26, 1.26] (by hand: the compiler would keep
+    asm("v_fma_f64 %0, -|%1|, %2, %3" : "=v"(e) : "v"(l), "s"(1.26), "v"(g));   // |l| of the whole segment in registers)
     bs = fma(l, dz[u], bs);                     // ... at p = s: beta_j after the move
     acc |= (uint32_t)__double2hiint(e) | (uint32_t)__double2hiint(bs);
   }
 }
 
-// the same with the test's half-width per move (2.51, or 0 for a move that is not to be tested: with dz = z_c = 0 it then
+// the same with the test's half-width per move (1.26, or 0 for a move that is not to be tested: with dz = z_c = 0 it then
 // changes nothing and passes): the cheap pass taken again behind a move redone exactly, whose half-block is partly done
 template <int H>
 __device__ __forceinline__ void run_load_k(const double* zk, double (&kk)[8])
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
           /* to test), the others are tested as ever */                                                                     \
           {                                                                                                                 \
             const bool inr = lane >= start && lane < mcnt;                                                                  \
-            zk[lane] = inr ? 2.51 : 0.0;                                                                                    \
+            zk[lane] = inr ? 1.26 : 0.0;                                                                                    \
             if (!inr) *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(0.0, 0.0);                                  \
             WAVE_SYNC();                                                                                                    \
           }                                                                                                                 \
