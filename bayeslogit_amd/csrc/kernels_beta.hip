@@ -1788,14 +1788,12 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
   // per lane, one and two segments ahead: the coordinate of move `lane` (its column offset, for the fetch) and its first normal
   int cq_n, cq_nn, co_n;
   double sq_n;
-#define BL_TABLE(dst, gg)             /* lane i: coordinate of move i of segment gg (scan gg / nseg, moves 64 (gg % nseg) ...) */ \
+#define BL_TABLE(dst, gg, kk_, qq_)   /* lane i: coordinate of move i of segment gg = (scan kk_, moves 64 qq_ ...) */       \
   {                                                                                                                         \
-    const int kk_ = (gg) / nseg, qq_ = (gg) - kk_ * nseg;                                                                   \
     dst = ((gg) < total && lane < P - 64 * qq_) ? (int)tab[(size_t)kk_ * P + 64 * qq_ + lane] : 0;                          \
   }
-#define BL_FETCH_HEAD(gg)             /* segment gg's normals; its column offsets (coordinates in cq_n) */                  \
+#define BL_FETCH_HEAD(gg, kk_, qq_)   /* segment gg = (scan kk_, moves 64 qq_ ...): its normals; its column offsets (coordinates in cq_n) */\
   {                                                                                                                         \
-    const int kk_ = (gg) / nseg, qq_ = (gg) - kk_ * nseg;                                                                   \
     sq_n = ((gg) < total && lane < P - 64 * qq_) ? rec[((size_t)kk_ * P + 64 * qq_ + lane) * kRec + 3] : 0.0;               \
     co_n = cq_n * (int)P8;                                                                                                  \
   }
@@ -1900,8 +1898,10 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     const double z1q = has ? sz[cq] : 0.0;                                                                                  \
     const double dzq = has ? sq - z1q : 0.0;                                                                                \
     *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(dzq, z1q);                                                    \
-    BL_TABLE(cq_nn, (g) + 2)                                                                                                \
-    BL_FETCH_HEAD((g) + 1)         /* (past the last segment: column 0 again, harmless) */                                  \
+    const int q1_ = (q) + 1 == nseg ? 0 : (q) + 1, k1_ = (q) + 1 == nseg ? (k) + 1 : (k);      /* the next segment, the one after */\
+    const int q2_ = q1_ + 1 == nseg ? 0 : q1_ + 1, k2_ = q1_ + 1 == nseg ? k1_ + 1 : k1_;                                   \
+    BL_TABLE(cq_nn, (g) + 2, k2_, q2_)                                                                                      \
+    BL_FETCH_HEAD((g) + 1, k1_, q1_)   /* (past the last segment: column 0 again, harmless) */                              \
     WAVE_SYNC();                                                                                                            \
     if (!spec_on) {                                                                                                         \
       BL_FETCH_ALL(nxt)                                                                                                     \
@@ -1981,10 +1981,10 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
   }
 
   double colA[64], colB[64];
-  BL_TABLE(cq_n, 0)
-  BL_TABLE(cq_nn, 1)
+  BL_TABLE(cq_n, 0, 0, 0)
+  BL_TABLE(cq_nn, 1, (nseg == 1 ? 1 : 0), (nseg == 1 ? 0 : 1))
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  BL_FETCH_HEAD(0)
+  BL_FETCH_HEAD(0, 0, 0)
   BL_FETCH_ALL(colA)
   int k = 0, q = 0;
   for (int g = 0; g < total; g += 2) {
