@@ -884,56 +884,9 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
   return b;
 }
 
-// One speculative group of the constrained sweeps (see k_beta64): beta after each of the group's moves on the
-// fast path (bs_out: after all of them) and the bound test of moves 2W and 2W+1 of the group.  Returns true if
-// both pass in every lane.
-template <int W, int G>
-__device__ __forceinline__ bool spec_group(const double* S, const double* Ri, const double* A, int ld, int lane, int i0,
-                                           int cvec, double svec, double z1v, double dzv, double bj, double& bs_out)
-{
-  constexpr int M = G / 4, u0 = W * M;          // this wavefront tests moves u0 .. u0 + M - 1 of the group
-  double lg[G];
-#pragma unroll
-  for (int u = 0; u < G; ++u) lg[u] = L_(S, lane, __builtin_amdgcn_readlane(cvec, i0 + u));
-  double rl[M], rh[M], sm[M], zm[M], bm[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int c = __builtin_amdgcn_readlane(cvec, i0 + u0 + m);
-    rl[m] = L_(Ri, lane, c);
-    rh[m] = L_(A, lane, c);
-    sm[m] = readlane_f64(svec, i0 + u0 + m);
-    zm[m] = readlane_f64(z1v, i0 + u0 + m);
-    bm[m] = bj;
-  }
-  double bs = bj;
-#pragma unroll
-  for (int u = 0; u < G; ++u) {
-    if (u >= u0 && u < u0 + M) bm[u - u0] = bs;
-    bs += lg[u] * readlane_f64(dzv, i0 + u);
-  }
-  bs_out = bs;
-  uint64_t acc = 0ull;
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const double lo = zm[m] - bm[m] * rl[m], hi = zm[m] - bm[m] * rh[m];   // NaN: the row does not bound that side
-    // v_cmp masks (inactive lanes and NaN operands give 0), ORed on the scalar unit; 2: ogt, 4: olt
-    acc |= __builtin_amdgcn_fcmp(lo, sm[m], 2) | __builtin_amdgcn_fcmp(hi, sm[m], 4) |
-           __builtin_amdgcn_fcmp(lo, -1.26, 2) | __builtin_amdgcn_fcmp(hi, 1.26, 4);
-  }
-  return acc == 0ull;
-}
-template <int G>
-__device__ __forceinline__ bool spec_group_w(int wave, const double* S, const double* Ri, const double* A, int ld, int lane,
-                                             int i0, int cvec, double svec, double z1v, double dzv, double bj,
-                                             double& bs_out)
-{
-  switch (wave) {
-    case 0: return spec_group<0, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
-    case 1: return spec_group<1, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
-    case 2: return spec_group<2, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
-    default: return spec_group<3, G>(S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs_out);
-  }
-}
+// one scan of the constrained sweeps on one wavefront (defined with k_beta_sweeps_run's pieces, below)
+__device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lane, int cvec, double svec, double z1v,
+                                         const double* Rk, double* zw, double* zk, double* zz, double& bj);
 
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
@@ -1151,12 +1104,11 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
-  __shared__ int gflag[2][4];
+  __shared__ double s_zw[128], s_zk[64], s_bj[64];     // solo_scan's hand-over slots; beta and the count it leaves for the other waves
+  __shared__ int s_nf;
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
   bool spec_on = true;
-  int gmax = 32;                                   // largest group of the scan
-  unsigned gi = 0;                                 // speculative groups so far (flag slot parity)
   for (int k = 0; k < P; ++k) {
     const double* Rk = recL + (k & 1) * nrec;
     // next scan's records: global -> registers now, -> LDS at the end of this scan
@@ -1175,41 +1127,19 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
     const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
     const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
-    const double dzv = svec - z1v;
-    int nfail = 0;                                                 // moves redone move by move in this scan
-    for (int i0 = 0; i0 < P;) {
-      const int left = P - i0;
-      // groups of 32, 16 or 8 moves (a quarter of them tested by each wavefront); a shorter tail goes move by move
-      const int ng = !spec_on ? (left < 8 ? left : 8) : (left >= 32 && gmax >= 32) ? 32 : (left >= 16 && gmax >= 16) ? 16 : left >= 8 ? 8 : left;
-      const bool spec = spec_on && ng >= 8;
-      double bs = bj;
-      bool all_ok = false;
-      if (spec) {
-        bool ok_l = true;
-        if (row) {
-          if (ng == 32)
-            ok_l = spec_group_w<32>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
-          else if (ng == 16)
-            ok_l = spec_group_w<16>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
-          else
-            ok_l = spec_group_w<8>(wave, S, Ri, A, ld, lane, i0, cvec, svec, z1v, dzv, bj, bs);
-        }
-        const bool okw = __ballot(!ok_l) == 0ull;                  // this wavefront's moves
-        if (lane == 0) gflag[gi & 1][wave] = okw ? 0 : 1;
-        __syncthreads();
-        const int* gf = gflag[gi & 1];
-        all_ok = __builtin_amdgcn_readfirstlane(gf[0] | gf[1] | gf[2] | gf[3]) == 0;
-        ++gi;
+    int nfail = 0;                                                 // moves taken with their exact bounds in this scan
+    if (spec_on) {
+      // the scan as one speculative segment on wavefront 0 (the others stage the next records and wait)
+      if (wave == 0) {
+        nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw, s_zk, zz, bj);
+        s_bj[lane] = bj;
+        if (lane == 0) s_nf = nfail;
       }
-      if (all_ok) {
-        bj = bs;
-        if (wave == 0 && row && lane >= i0 && lane < i0 + ng) zz[cvec] = svec;
-        i0 += ng;
-        continue;
-      }
-      nfail += ng;
+    } else {
+      // a chain pressed against its bounds: move by move, every wavefront alike (same inputs, same arithmetic: the replicas
+      // of beta stay identical without an exchange)
       const int lr = row ? lane : 0;                               // lanes outside the matrix read row 0, masked below
-      for (int i = i0; i < i0 + ng; ++i) {
+      for (int i = 0; i < P; ++i) {
         const int c = __builtin_amdgcn_readlane(cvec, i);
         const double l1 = row ? L_(S, lr, c) : 0.0, rl = row ? L_(Ri, lr, c) : qnan, rh = row ? L_(A, lr, c) : qnan;
         const double* Rn = Rk + i * kRec + g4;
@@ -1228,17 +1158,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           lo = lo == lo ? lo : -inf;
           hi = hi == hi ? hi : inf;
           z2 = tnorm_lanes(r0, r1, r2, r3, lane, lo, hi);
+          ++nfail;
         }
         const double dz = z2 - z1;
         bj += l1 * dz;                 // L(j, c) = 0 for j < c and l1 = 0 outside the matrix: those rows do not move
         if (wave == 0 && lane == 0) zz[c] = z2;
       }
-      i0 += ng;
     }
-    // a chain pressed against its bounds fails most groups: stop speculating, look again every 8th scan
-    spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
-    gmax = nfail == 0 ? 32 : 8;                                    // failures come in runs (a coordinate at its bound): small groups then
-    if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
     if (k + 1 < P) {
       double* Rn = recL + ((k + 1) & 1) * nrec;
 #pragma unroll
@@ -1248,6 +1174,14 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       }
     }
     __syncthreads();
+    if (spec_on) {                       // wavefront 0's scan: its beta and its count to every replica
+      bj = s_bj[lane];
+      nfail = s_nf;
+    }
+    __syncthreads();                     // (s_bj, s_nf are rewritten by the next scan)
+    // a chain pressed against its bounds gains nothing from speculating: move by move then, look again every 8th scan
+    spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
+    if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
   }
   if (wave == 0 && row) a.beta_out[lane] = bj;
   if (a.dbg && t == 0) a.dbg[6] = wall_clock64();
@@ -1614,6 +1548,7 @@ struct ExactIn {
 // mask of the moves that fail all three somewhere in the matrix (wave-uniform, the same in every wave) and, in bb, the
 // chain value just before the first of them (after the half-block if there is none); for that move the exact path's
 // inputs go into x (its tnorm record is requested here, its entry of L is in the registers).
+template <bool SOLO>     // SOLO: one wavefront holds every row (P <= 64): nothing to exchange, no barrier
 __device__ __forceinline__ uint32_t run_half(const double (&l8)[8], int H, double bs, bool lastrow, int lane, int wave,
                                              int start, int mcnt, const double* zw, uint32_t* x1, unsigned& par,
                                              const double* __restrict__ RkSeg, int g4, double& bb, ExactIn& x)
@@ -1642,13 +1577,16 @@ __device__ __forceinline__ uint32_t run_half(const double (&l8)[8], int H, doubl
     b = es;
   }
   uint32_t pk = lastrow ? 0u : (pA | pB | pC);                       // row P-1 is not constrained (Logit.hpp:383: j < P-1)
-  pk = wave_or_u32(pk);
-  uint32_t* slot = x1 + par * 4;
-  if (lane == 0) slot[wave] = pk & (valid * 0x010101u);
-  __syncthreads();
-  const uint4 sv = *reinterpret_cast<const uint4*>(slot);
-  par ^= 1u;
-  const uint32_t m = sv.x | sv.y | sv.z | sv.w;
+  pk = wave_or_u32(pk) & (valid * 0x010101u);
+  uint32_t m = pk;
+  if (!SOLO) {
+    uint32_t* slot = x1 + par * 4;
+    if (lane == 0) slot[wave] = pk;
+    __syncthreads();
+    const uint4 sv = *reinterpret_cast<const uint4*>(slot);
+    par ^= 1u;
+    m = sv.x | sv.y | sv.z | sv.w;
+  }
   const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)(m & (m >> 8) & (m >> 16) & 0xFFu));
   int n = 8;
   if (f != 0u) {
@@ -1672,6 +1610,7 @@ __device__ __forceinline__ uint32_t run_half(const double (&l8)[8], int H, doubl
 }
 
 // move mf of the segment with its exact bounds (Logit.hpp:383-397), its inputs in x: split_exact's arithmetic
+template <bool SOLO>
 __device__ __forceinline__ void run_exact(const ExactIn& x, int mf, int cq, double z1q, bool lastrow, int lane, int wave,
                                           int nq, double& bj, double* sz, double* xl, unsigned& par)
 {
@@ -1683,18 +1622,23 @@ __device__ __forceinline__ void run_exact(const ExactIn& x, int mf, int cq, doub
   const double rl = (x.l1 > 0.0 && !lastrow) ? rcp : nan, rh = (x.l1 < 0.0 && !lastrow) ? rcp : nan;
   double lo = z1 - bj * rl, hi = z1 - bj * rh;       // NaN: this row does not bound the move on that side
   wave_maxmin(lo, hi);
-  double* sl = xl + par * 8;
-  if (lane == 0) {
-    sl[wave * 2] = lo;
-    sl[wave * 2 + 1] = hi;
-  }
-  __syncthreads();
   double glo = -__builtin_huge_val(), ghi = __builtin_huge_val();
-  for (int w = 0; w < nq; ++w) {
-    glo = vmax64(glo, sl[w * 2]);            // v_max_f64 / v_min_f64 return the other operand for a NaN
-    ghi = vmin64(ghi, sl[w * 2 + 1]);
+  if (SOLO) {
+    glo = vmax64(glo, lo);                   // v_max_f64 / v_min_f64 return the other operand for a NaN
+    ghi = vmin64(ghi, hi);
+  } else {
+    double* sl = xl + par * 8;
+    if (lane == 0) {
+      sl[wave * 2] = lo;
+      sl[wave * 2 + 1] = hi;
+    }
+    __syncthreads();
+    for (int w = 0; w < nq; ++w) {
+      glo = vmax64(glo, sl[w * 2]);
+      ghi = vmin64(ghi, sl[w * 2 + 1]);
+    }
+    par ^= 1u;
   }
-  par ^= 1u;
   const double z2 = tnorm_lanes(x.r0, x.r1, x.r2, x.r3, lane, glo, ghi);
   bj += x.l1 * (z2 - z1);
   if (wave == 0 && lane == 0) sz[c] = z2;
@@ -1742,6 +1686,178 @@ __global__ __launch_bounds__(1024) void k_beta_scan_tables(blk::BetaArgs a)
     Bf = tmp;
   }
   for (int e = t; e < P * P + 128; e += nthr) tab[e] = e < P * P ? (uint32_t)A[e] : 0u;
+}
+
+// one cheap pass over the whole half-blocks h0 .. nbw-1 of the segment: the chain value at the end (bs) and at the
+// half-blocks' starts (cp1..cp7; one not run leaves the value as it is), the half-blocks that failed somewhere in the
+// matrix (Fb, the same in every wave)
+#define BL_CALC(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                         \
+    if ((h0) <= (H) && nbw > (H)) run_calc<H>(cur, dX, zX, bs, aX);                                                         \
+    FETCH(nxt, H)
+#define BL_CALC_K(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                       \
+    if ((h0) <= (H) && nbw > (H)) {                                                                                         \
+      double kk_[8];                                                                                                        \
+      run_load_k<H>(zk, kk_);                                                                                               \
+      run_calc_k<H>(cur, dX, zX, kk_, bs, aX);                                                                              \
+    }
+#define BL_PASS(cur, h0, CALC, FETCH, nxt, EXCH)                                                                            \
+  {                                                                                                                         \
+    double dA[8], zA[8], dB[8], zB[8];                                                                                      \
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;                                                \
+    bs = bj;                                                                                                                \
+    run_load<0>(zw, dA, zA);                                                                                                \
+    run_load<1>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 0, dA, zA, a0, FETCH, nxt)                                                                                \
+    cp1 = bs;                                                                                                               \
+    run_load<2>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 1, dB, zB, a1, FETCH, nxt)                                                                                \
+    cp2 = bs;                                                                                                               \
+    run_load<3>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 2, dA, zA, a2, FETCH, nxt)                                                                                \
+    cp3 = bs;                                                                                                               \
+    run_load<4>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 3, dB, zB, a3, FETCH, nxt)                                                                                \
+    cp4 = bs;                                                                                                               \
+    run_load<5>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 4, dA, zA, a4, FETCH, nxt)                                                                                \
+    cp5 = bs;                                                                                                               \
+    run_load<6>(zw, dA, zA);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 5, dB, zB, a5, FETCH, nxt)                                                                                \
+    cp6 = bs;                                                                                                               \
+    run_load<7>(zw, dB, zB);                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    CALC(cur, h0, 6, dA, zA, a6, FETCH, nxt)                                                                                \
+    cp7 = bs;                                                                                                               \
+    CALC(cur, h0, 7, dB, zB, a7, FETCH, nxt)                                                                                \
+    uint32_t vb = (a0 >> 31) | ((a1 >> 31) << 1) | ((a2 >> 31) << 2) | ((a3 >> 31) << 3) | ((a4 >> 31) << 4) |             \
+                  ((a5 >> 31) << 5) | ((a6 >> 31) << 6) | ((a7 >> 31) << 7);                                                \
+    if (lastrow) vb = 0u;                                                                                                   \
+    vb = wave_or_u32(vb);                                                                                                   \
+    EXCH(vb)                                                                                                                \
+  }
+#define BL_HALF(H, cp)                                                                                                      \
+    {                                                                                                                       \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) l8[u] = cur_[8 * (H) + u];                                              \
+      bs0 = start <= 8 * (H) ? cp : bj;                                                                                     \
+    }
+// the waves' verdicts of a pass meet in LDS (one word each, one barrier); SOLO: there is one wave
+#define BL_EXCH_WG(vb)                                                                                                      \
+    uint32_t* slot1 = x1 + par * 4;                                                                                         \
+    if (lane == 0) slot1[wave] = vb;                                                                                        \
+    __syncthreads();                                                                                                        \
+    const uint4 sv = *reinterpret_cast<const uint4*>(slot1);                                                                \
+    par ^= 1u;                                                                                                              \
+    Fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w)) | tailbit;
+#define BL_EXCH_SOLO(vb) Fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb) | tailbit;
+#define BL_NOFETCH(dst, G_)
+
+// the rare part of a segment: a cheap pass has left failing half-blocks in Fb.  In their order: the three tests on the
+// half-block; a move that fails them with its exact bounds; then everything behind that move again.  On exit bj is the
+// chain value at the segment's end, exm the moves redone exactly, nslow their count added up.
+#define BL_SLOW_LOOP(cur, SOLO, EXCH, NQW)                                                                                  \
+  {                                                                                                                         \
+  const double (&cur_)[64] = cur;                                                                                           \
+  int start = 0;                                                                                                            \
+  for (;;) {                                                                                                                \
+    if (Fb == 0u) {                                                                                                         \
+      bj = bs;                                                                                                              \
+      break;                                                                                                                \
+    }                                                                                                                       \
+    const int Hf = __builtin_ctz(Fb);                                                                                       \
+    const int bend = mcnt < 8 * Hf + 8 ? mcnt : 8 * Hf + 8;                                                                 \
+    uint32_t f;                                                                                                             \
+    double bb;                                                                                                              \
+    ExactIn xin;                                                                                                            \
+    if (prof) ++ncareful;                                                                                                   \
+    double l8[8], bs0;                                                                                                      \
+    switch (Hf) {                                                                                                           \
+      case 0: BL_HALF(0, bj) break;                                                                                         \
+      case 1: BL_HALF(1, cp1) break;                                                                                        \
+      case 2: BL_HALF(2, cp2) break;                                                                                        \
+      case 3: BL_HALF(3, cp3) break;                                                                                        \
+      case 4: BL_HALF(4, cp4) break;                                                                                        \
+      case 5: BL_HALF(5, cp5) break;                                                                                        \
+      case 6: BL_HALF(6, cp6) break;                                                                                        \
+      default: BL_HALF(7, cp7) break;                                                                                       \
+    }                                                                                                                       \
+    f = run_half<SOLO>(l8, Hf, bs0, lastrow, lane, wave, start, mcnt, zw, x1, par, RkSeg, g4, bb, xin);                     \
+    bj = bb;                                                                                                                \
+    if (f == 0u) {                           /* the chain is as the cheap pass had it: its other verdicts stand */          \
+      start = bend;                                                                                                         \
+      Fb &= ~(1u << Hf);                                                                                                    \
+      if (start >= mcnt) break;              /* that was the segment's last half-block: bj is the chain's end */            \
+      continue;                                                                                                             \
+    }                                                                                                                       \
+    const int nf = __builtin_ctz(f), mf = 8 * Hf + nf;     /* the first move that needs its bounds */                       \
+    const long long te0 = prof ? clock64() : 0;                                                                             \
+    run_exact<SOLO>(xin, mf, cq, z1q, lastrow, lane, wave, NQW, bj, sz, xl, par);                                           \
+    if (prof) tExact += clock64() - te0;                                                                                    \
+    exm |= 1ull << mf;                                                                                                      \
+    nslow = __builtin_amdgcn_readfirstlane(nslow + 1);                                                                      \
+    start = mf + 1;                                                                                                         \
+    if (start >= mcnt) break;                                                                                               \
+    /* everything behind the move again, from its chain value, in one cheap pass: the moves done retire (dz = z_c = 0, nothing */\
+    /* to test), the others are tested as ever */                                                                           \
+    {                                                                                                                       \
+      const bool inr = lane >= start && lane < mcnt;                                                                        \
+      zk[lane] = inr ? 1.26 : 0.0;                                                                                          \
+      if (!inr) *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(0.0, 0.0);                                        \
+      WAVE_SYNC();                                                                                                          \
+    }                                                                                                                       \
+    if (prof) ++nrepass;                                                                                                    \
+    const long long tr0 = prof ? clock64() : 0;                                                                             \
+    BL_PASS(cur, Hf, BL_CALC_K, BL_NOFETCH, cur, EXCH)                                                                      \
+    if (prof) tRepass += clock64() - tr0;                                                                                   \
+  }                                                                                                                         \
+  }
+
+// One scan of the constrained sweeps for P <= 64 (Logit.hpp:380-398) on ONE wavefront -- lane = row, beta_j in a register; L,
+// z and the scan's records in LDS: k_beta_sweeps_run's speculative segment (the scan's P moves are one segment) with nothing
+// to exchange and nothing to fetch ahead.  Returns the number of moves redone with their exact bounds.
+__device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lane, int cvec, double svec, double z1v,
+                                         const double* Rk, double* zw, double* zk, double* zz, double& bj)
+{
+  const int mcnt = P, wave = 0;
+  const bool has = lane < P, lastrow = lane >= P - 1;       // row P-1 is not constrained (Logit.hpp:383: j < P-1)
+  const int lr = has ? lane : P - 1;                         // a lane past the matrix rides on row P-1, which no test looks at
+  const int cq = has ? cvec : 0, g4 = (lane < 5 ? lane : 0) * 4;
+  const double sq = svec, z1q = has ? z1v : 0.0, dzq = has ? sq - z1q : 0.0;
+  const double* RkSeg = Rk;
+  double* sz = zz;
+  uint32_t* x1 = nullptr;                                    // (the exchange slots of the four-wave kernel: unused)
+  double* xl = nullptr;
+  unsigned par = 0;
+  constexpr bool prof = false;
+  unsigned long long ncareful = 0, nrepass = 0;
+  long long tExact = 0, tRepass = 0;
+  int nslow = 0;
+  // the scan's columns of L, in the order of its moves: L(lr, c_u) for move u
+  double cur[64];
+  const int co = cq * ld;
+#pragma unroll
+  for (int u = 0; u < 64; ++u) cur[u] = S[__builtin_amdgcn_readlane(co, u) + lr];
+  *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(dzq, z1q);
+  WAVE_SYNC();
+  const int nbw = mcnt >> 3;                                      // whole half-blocks
+  const uint32_t tailbit = (mcnt & 7) ? (1u << nbw) : 0u;         // the one the scan's end cuts: the slow way
+  double bs, cp1, cp2, cp3, cp4, cp5, cp6, cp7;
+  uint32_t Fb;
+  BL_PASS(cur, 0, BL_CALC, BL_NOFETCH, cur, BL_EXCH_SOLO)
+  unsigned long long exm = 0ull;                                  // moves redone exactly (they wrote their own z)
+  if (Fb == 0u) {
+    bj = bs;
+  } else {
+    BL_SLOW_LOOP(cur, true, BL_EXCH_SOLO, 1)
+  }
+  if (has && !((exm >> lane) & 1ull)) sz[cq] = sq;
+  (void)ncareful; (void)nrepass; (void)tExact; (void)tRepass; (void)x1; (void)xl;
+  return nslow;
 }
 
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
@@ -1813,75 +1929,11 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     BL_FETCH_GROUP(dst, 0) BL_FETCH_GROUP(dst, 1) BL_FETCH_GROUP(dst, 2) BL_FETCH_GROUP(dst, 3)                             \
     BL_FETCH_GROUP(dst, 4) BL_FETCH_GROUP(dst, 5) BL_FETCH_GROUP(dst, 6) BL_FETCH_GROUP(dst, 7)                             \
   }
-#define BL_NOFETCH(dst, G_)
   const bool prof = a.dbg != nullptr;
   unsigned long long nexact = 0, ncareful = 0, nrepass = 0;
   long long tPass = 0, tSlow = 0, tExact = 0, tRepass = 0, tAll = prof ? clock64() : 0;
   int nslow = 0, noff = 0;     // moves of the scan redone exactly; scans in which a third of the moves were
 
-  // one cheap pass over the whole half-blocks h0 .. nbw-1 of the segment: the chain value at the end (bs) and at the
-  // half-blocks' starts (cp1..cp7; one not run leaves the value as it is), the half-blocks that failed somewhere in the
-  // matrix (Fb, the same in every wave)
-#define BL_CALC(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                         \
-    if ((h0) <= (H) && nbw > (H)) run_calc<H>(cur, dX, zX, bs, aX);                                                         \
-    FETCH(nxt, H)
-#define BL_CALC_K(cur, h0, H, dX, zX, aX, FETCH, nxt)                                                                       \
-    if ((h0) <= (H) && nbw > (H)) {                                                                                         \
-      double kk_[8];                                                                                                        \
-      run_load_k<H>(zk, kk_);                                                                                               \
-      run_calc_k<H>(cur, dX, zX, kk_, bs, aX);                                                                              \
-    }
-#define BL_PASS(cur, h0, CALC, FETCH, nxt)                                                                                  \
-  {                                                                                                                         \
-    double dA[8], zA[8], dB[8], zB[8];                                                                                      \
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;                                                \
-    bs = bj;                                                                                                                \
-    run_load<0>(zw, dA, zA);                                                                                                \
-    run_load<1>(zw, dB, zB);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 0, dA, zA, a0, FETCH, nxt)                                                                                \
-    cp1 = bs;                                                                                                               \
-    run_load<2>(zw, dA, zA);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 1, dB, zB, a1, FETCH, nxt)                                                                                \
-    cp2 = bs;                                                                                                               \
-    run_load<3>(zw, dB, zB);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 2, dA, zA, a2, FETCH, nxt)                                                                                \
-    cp3 = bs;                                                                                                               \
-    run_load<4>(zw, dA, zA);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 3, dB, zB, a3, FETCH, nxt)                                                                                \
-    cp4 = bs;                                                                                                               \
-    run_load<5>(zw, dB, zB);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 4, dA, zA, a4, FETCH, nxt)                                                                                \
-    cp5 = bs;                                                                                                               \
-    run_load<6>(zw, dA, zA);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 5, dB, zB, a5, FETCH, nxt)                                                                                \
-    cp6 = bs;                                                                                                               \
-    run_load<7>(zw, dB, zB);                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                                                      \
-    CALC(cur, h0, 6, dA, zA, a6, FETCH, nxt)                                                                                \
-    cp7 = bs;                                                                                                               \
-    CALC(cur, h0, 7, dB, zB, a7, FETCH, nxt)                                                                                \
-    uint32_t vb = (a0 >> 31) | ((a1 >> 31) << 1) | ((a2 >> 31) << 2) | ((a3 >> 31) << 3) | ((a4 >> 31) << 4) |             \
-                  ((a5 >> 31) << 5) | ((a6 >> 31) << 6) | ((a7 >> 31) << 7);                                                \
-    if (lastrow) vb = 0u;                                                                                                   \
-    vb = wave_or_u32(vb);                                                                                                   \
-    uint32_t* slot1 = x1 + par * 4;                                                                                         \
-    if (lane == 0) slot1[wave] = vb;                                                                                        \
-    __syncthreads();                                                                                                        \
-    const uint4 sv = *reinterpret_cast<const uint4*>(slot1);                                                                \
-    par ^= 1u;                                                                                                              \
-    Fb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sv.x | sv.y | sv.z | sv.w)) | tailbit;                              \
-  }
-#define BL_HALF(H, cp)                                                                                                      \
-    {                                                                                                                       \
-      _Pragma("unroll") for (int u = 0; u < 8; ++u) l8[u] = cur_[8 * (H) + u];                                              \
-      bs0 = start <= 8 * (H) ? cp : bj;                                                                                     \
-    }
   // one segment: `cur` holds its columns, `nxt` receives the next segment's
 #define BL_SEGMENT(cur, nxt, g, k, q)                                                                                       \
   {                                                                                                                         \
@@ -1914,66 +1966,14 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
       uint32_t Fb;                                                                                                          \
       /* the first pass in line (a loop header here would wait for the fetch just issued); what follows it is rare */       \
       const long long tp0 = prof ? clock64() : 0;                                                                           \
-      BL_PASS(cur, 0, BL_CALC, BL_FETCH_GROUP, nxt)   /* the next segment's columns are requested between the half-blocks */\
+      BL_PASS(cur, 0, BL_CALC, BL_FETCH_GROUP, nxt, BL_EXCH_WG)   /* the next segment's columns are requested between the half-blocks */\
       if (prof) tPass += clock64() - tp0;                                                                                   \
       unsigned long long exm = 0ull;                                  /* moves redone exactly (they wrote their own z) */   \
       if (Fb == 0u) {                                                                                                       \
         bj = bs;                                                                                                            \
       } else {                                                                                                              \
         const long long ts0 = prof ? clock64() : 0;                                                                         \
-        const double (&cur_)[64] = cur;                                                                                     \
-        int start = 0;                                                                                                      \
-        for (;;) {                                                                                                          \
-          if (Fb == 0u) {                                                                                                   \
-            bj = bs;                                                                                                        \
-            break;                                                                                                          \
-          }                                                                                                                 \
-          const int Hf = __builtin_ctz(Fb);                                                                                 \
-          const int bend = mcnt < 8 * Hf + 8 ? mcnt : 8 * Hf + 8;                                                           \
-          uint32_t f;                                                                                                       \
-          double bb;                                                                                                        \
-          ExactIn xin;                                                                                                      \
-          if (prof) ++ncareful;                                                                                             \
-          double l8[8], bs0;                                                                                                \
-          switch (Hf) {                                                                                                     \
-            case 0: BL_HALF(0, bj) break;                                                                                   \
-            case 1: BL_HALF(1, cp1) break;                                                                                  \
-            case 2: BL_HALF(2, cp2) break;                                                                                  \
-            case 3: BL_HALF(3, cp3) break;                                                                                  \
-            case 4: BL_HALF(4, cp4) break;                                                                                  \
-            case 5: BL_HALF(5, cp5) break;                                                                                  \
-            case 6: BL_HALF(6, cp6) break;                                                                                  \
-            default: BL_HALF(7, cp7) break;                                                                                 \
-          }                                                                                                                 \
-          f = run_half(l8, Hf, bs0, lastrow, lane, wave, start, mcnt, zw, x1, par, RkSeg, g4, bb, xin);                     \
-          bj = bb;                                                                                                          \
-          if (f == 0u) {                           /* the chain is as the cheap pass had it: its other verdicts stand */    \
-            start = bend;                                                                                                   \
-            Fb &= ~(1u << Hf);                                                                                              \
-            if (start >= mcnt) break;              /* that was the segment's last half-block: bj is the chain's end */      \
-            continue;                                                                                                       \
-          }                                                                                                                 \
-          const int nf = __builtin_ctz(f), mf = 8 * Hf + nf;     /* the first move that needs its bounds */                 \
-          const long long te0 = prof ? clock64() : 0;                                                                       \
-          run_exact(xin, mf, cq, z1q, lastrow, lane, wave, NQ, bj, sz, xl, par);                                            \
-          if (prof) tExact += clock64() - te0;                                                                              \
-          exm |= 1ull << mf;                                                                                                \
-          nslow = __builtin_amdgcn_readfirstlane(nslow + 1);                                                                \
-          start = mf + 1;                                                                                                   \
-          if (start >= mcnt) break;                                                                                         \
-          /* everything behind the move again, from its chain value, in one cheap pass: the moves done retire (dz = z_c = 0, nothing */\
-          /* to test), the others are tested as ever */                                                                     \
-          {                                                                                                                 \
-            const bool inr = lane >= start && lane < mcnt;                                                                  \
-            zk[lane] = inr ? 1.26 : 0.0;                                                                                    \
-            if (!inr) *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(0.0, 0.0);                                  \
-            WAVE_SYNC();                                                                                                    \
-          }                                                                                                                 \
-          if (prof) ++nrepass;                                                                                              \
-          const long long tr0 = prof ? clock64() : 0;                                                                       \
-          BL_PASS(cur, Hf, BL_CALC_K, BL_NOFETCH, nxt)                                                                      \
-          if (prof) tRepass += clock64() - tr0;                                                                             \
-        }                                                                                                                   \
+        BL_SLOW_LOOP(cur, false, BL_EXCH_WG, NQ)                                                                            \
         if (prof) tSlow += clock64() - ts0;                                                                                 \
       }                                                                                                                     \
       if (wave == 0 && has && !((exm >> lane) & 1ull)) sz[cq] = sq;                                                         \
@@ -2025,11 +2025,6 @@ __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
     a.dbg[18] = (unsigned long long)tSlow;
   }
 #undef BL_SEGMENT
-#undef BL_HALF
-#undef BL_PASS
-#undef BL_CALC_K
-#undef BL_CALC
-#undef BL_NOFETCH
 #undef BL_FETCH_ALL
 #undef BL_FETCH_GROUP
 #undef BL_FETCH_HEAD
