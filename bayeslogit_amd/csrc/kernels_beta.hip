@@ -1086,19 +1086,16 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
   // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
   //
-  // Speculative groups on four wavefronts.  Moves are taken 16 (or 8) at a time on the fast path: every
-  // move of the group is assumed to take attempt 0's normal s (which is what a move whose bounds contain 0,
-  // are wider than sqrt(2 pi) and contain s does).  A group is straight-line code: its loads and broadcasts
-  // first, one dependent FMA per move (beta after u moves), and a move's test -- every lane's lower
-  // candidate <= min(s, -1.26) and upper candidate >= max(s, 1.26), the first of the three tests above --
-  // only ORs compare masks into a scalar.  One wavefront issues an instruction every ~8 cycles here, so the
-  // FOUR wavefronts of the workgroup (one per SIMD) each keep a replica of beta (lane j = row j), all run
-  // the one-FMA-per-move chain, and each tests a quarter of the group's moves; the verdicts meet in LDS at one
-  // barrier per group.  A group with a failing move (a few per draw on C4) is redone move by move with all
-  // three tests and the full tnorm, by every wavefront alike (same inputs, same arithmetic: the replicas
-  // stay identical without another exchange).  Same values as the move-by-move loop either way.
+  // One speculative segment per scan, on wavefront 0 (solo_scan): every move of the scan is assumed to take attempt 0's
+  // normal s, so dz = s - z_c is known for the whole scan up front; the chain beta_j + L_jc dz runs move by move in
+  // registers with the first of the three tests above in feasibility form beside it (three FMAs and an OR per move, sign
+  // bits per half-block of 8), a failing half-block goes through the three tests, a move that fails those is redone with
+  // its bounds and everything behind it is taken again.  The other wavefronts stage the next scan's records meanwhile and
+  // receive beta through LDS at the scan's end.  A chain pressed against its bounds gains nothing from that: its scans go
+  // move by move on every wavefront alike (same inputs, same arithmetic: the replicas of beta stay identical without an
+  // exchange).  Same values as the move-by-move loop either way.
   // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
-  // moves are gathered at its start (z1v) and a group's new values are scattered at its end.
+  // moves are gathered at its start (z1v) and the new values are scattered at its end.
   const int lane = t & 63, wave = t >> 6;
   const bool row = lane < P;
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront

@@ -86,10 +86,11 @@ def test_one_sweep_matches_oracle(gpu, oracle, N, P):
 @pytest.mark.parametrize("P", [64, 63, 56, 40, 33, 24, 9, 8, 7])
 @pytest.mark.parametrize("lo,hi", [(0.6, 1.6), (0.0, 0.3), (0.0, 0.02)])
 def test_constrained_draw_group_sizes(gpu, oracle, P, lo, hi):
-    """The constrained draw takes its P^2 coordinate moves in speculative groups of 32, 16 or 8 (a shorter
-    tail and every group with a move that needs the bounds go move by move): every split of P, with
-    beta_prev well inside the constraint region (all groups confirmed), near it, and on it (most groups
-    redone, then speculation switched off) against the oracle's move-by-move draw, several sweeps chained."""
+    """The constrained draw (P <= 64) takes the P moves of a scan as one speculative segment (whole half-blocks of 8
+    through the cheap test, a half-block the end of the scan cuts and every failing one through the three tests, a
+    move that needs its bounds exactly): every P and tail length, with beta_prev well inside the constraint region
+    (every segment confirmed), near it, and on it (most scans redone, then speculation switched off) against the
+    oracle's move-by-move draw, several sweeps chained."""
     from bayeslogit_amd import device as D
     N = 40 * P
     X, y, n = synth(N, P, 3 * P + int(100 * hi), nmax=2)
