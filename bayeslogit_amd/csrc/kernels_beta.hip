@@ -777,7 +777,7 @@ __device__ bool w_chol_lower(double* S, int P, int ld, int lane)
 // a_ij -= u_ki u_kj, k ascending (a product of the same two numbers either way round) -- so the factor is
 // bit-identical; LOWER = false: A = U'U, reads and writes the upper triangle of M; LOWER = true: M = L L', reads
 // the lower triangle of M (row i of the transposed problem is column i of the lower triangle), writes L = U'
-// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS.  Measured in k_beta64: 65 us each
+// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS, 16-byte aligned.  Measured in k_beta64: 65 us each
 // against 130 for w_chol_upper / w_chol_lower.
 template <bool LOWER>
 __device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
@@ -789,9 +789,16 @@ __device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
     r[j] = in ? (LOWER ? L_(M, j, lane) : L_(M, lane, j)) : 0.0;
   }
   for (int k = 0; k < P; ++k) {
+    // the pivot row to LDS: the columns from k on, in pairs, by groups of 8 (a group wholly left of k is finished: zeros
+    // in the update below)
     if (lane == k) {
 #pragma unroll
-      for (int j = 0; j < 64; ++j) buf[j] = r[j];
+      for (int g8 = 0; g8 < 8; ++g8)
+        if (8 * g8 + 7 >= k && 8 * g8 < P) {
+#pragma unroll
+          for (int jj = 0; jj < 8; jj += 2)
+            *reinterpret_cast<double2*>(buf + 8 * g8 + jj) = make_double2(r[8 * g8 + jj], r[8 * g8 + jj + 1]);
+        }
     }
     WAVE_SYNC();
     const double akk = buf[k];
@@ -808,8 +815,17 @@ __device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
     }
     buf[lane] = u;                                 // u_kj for j > k, 0 for j <= k and outside the matrix
     WAVE_SYNC();
+    // (rows i <= k have u = 0: unchanged; so are the columns j <= k, where u_kj = 0: their groups are skipped)
 #pragma unroll
-    for (int j = 0; j < 64; ++j) r[j] = fma(-u, buf[j], r[j]);     // rows i <= k have u = 0: unchanged
+    for (int g8 = 0; g8 < 8; ++g8)
+      if (8 * g8 + 7 > k && 8 * g8 < P) {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj += 2) {
+          const double2 b2 = *reinterpret_cast<const double2*>(buf + 8 * g8 + jj);
+          r[8 * g8 + jj] = fma(-u, b2.x, r[8 * g8 + jj]);
+          r[8 * g8 + jj + 1] = fma(-u, b2.y, r[8 * g8 + jj + 1]);
+        }
+      }
     WAVE_SYNC();
   }
   if (LOWER) {
@@ -904,6 +920,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   int* ptab = perm + P + (P & 1);                    // ptab[k][i]: coordinate visited at step i of scan k (P*P ints)
   double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
+  __shared__ __attribute__((aligned(16))) double s_piv[64];   // w_chol_reg's pivot row
   __shared__ int bad;
   __shared__ int uflag;                              // 0: U not ready; 1: U = chol(PP) is in A; 2: PP not positive definite
   if (t == 0) bad = 0;
@@ -947,7 +964,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (t < 64) {
     // ================= wave 0: the dense stage, alone, no workgroup barriers =================
     const int lane = t;
-    bool ok = w_chol_reg<false>(A, P, ld, lane, recL);                        // U = chol(PP,'U') (recL is idle until the sweeps)
+    bool ok = w_chol_reg<false>(A, P, ld, lane, s_piv);                       // U = chol(PP,'U')
     // wave 1 solves for mP from U once its own work is done (it idles otherwise): hand U over
     __threadfence_block();
     if (lane == 0) __hip_atomic_store(&uflag, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -974,7 +991,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       } else {
         // B_CONSTRAINED set-up, Logit.hpp:335-366 (mP: wave 1; z: after the barrier, when mP is there)
         if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
-        ok = w_chol_reg<true>(S, P, ld, lane, recL);                          // L = chol(S,'L')
+        ok = w_chol_reg<true>(S, P, ld, lane, s_piv);                         // L = chol(S,'L')
         if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
       }
     }
@@ -1101,7 +1118,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
-  __shared__ double s_zw[128], s_zk[64], s_bj[64];     // solo_scan's hand-over slots; beta and the count it leaves for the other waves
+  __shared__ __attribute__((aligned(16))) double s_zw[128], s_zk[64], s_bj[64];     // solo_scan's hand-over slots; beta and the count it leaves for the other waves
   __shared__ int s_nf;
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
