@@ -754,6 +754,14 @@ __device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int 
     const double* ui = U + i * ld;                         // column i of U: U[k][i], k < i
     double acc = col[i];
     int k = 0;
+    // sixteen products in flight (one LDS round trip per sixteen: with four the loop was latency-bound), subtracted in order
+    for (; k + 15 < i; k += 16) {
+      double pr[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pr[q] = ui[k + q] * col[k + q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc = acc - pr[q];
+    }
     for (; k + 3 < i; k += 4) {
       const double p0 = ui[k] * col[k], p1 = ui[k + 1] * col[k + 1], p2 = ui[k + 2] * col[k + 2], p3 = ui[k + 3] * col[k + 3];
       acc = (((acc - p0) - p1) - p2) - p3;
@@ -765,6 +773,13 @@ __device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int 
   for (int i = P - 1; i >= 0; --i) {                       // backward: U x = y
     double acc = col[i];
     int k = i + 1;
+    for (; k + 15 < P; k += 16) {
+      double pr[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pr[q] = L_(U, i, k + q) * col[k + q];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc = acc - pr[q];
+    }
     for (; k + 3 < P; k += 4) {
       const double p0 = L_(U, i, k) * col[k], p1 = L_(U, i, k + 1) * col[k + 1], p2 = L_(U, i, k + 2) * col[k + 2],
                    p3 = L_(U, i, k + 3) * col[k + 3];
