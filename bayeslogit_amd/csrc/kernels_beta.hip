@@ -1042,8 +1042,8 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
-  __shared__ __attribute__((aligned(16))) double s_zw[128], s_zk[64], s_bj[64];     // solo_scan's hand-over slots; beta and the count it leaves for the other waves
-  __shared__ int s_nf;
+  __shared__ __attribute__((aligned(16))) double s_zw[128], s_zk[64], s_bj[2][64];  // solo_scan's hand-over slots; beta and the count it leaves for the other waves
+  __shared__ int s_nf[2];                                                            // (by scan parity: one barrier per scan)
   for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
   __syncthreads();
   bool spec_on = true;
@@ -1070,8 +1070,8 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       // the scan as one speculative segment on wavefront 0 (the others stage the next records and wait)
       if (wave == 0) {
         nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw, s_zk, zz, bj);
-        s_bj[lane] = bj;
-        if (lane == 0) s_nf = nfail;
+        s_bj[k & 1][lane] = bj;
+        if (lane == 0) s_nf[k & 1] = nfail;
       }
     } else {
       // a chain pressed against its bounds: move by move, every wavefront alike (same inputs, same arithmetic: the replicas
@@ -1112,13 +1112,11 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       }
     }
     __syncthreads();
-    if (spec_on) {                       // wavefront 0's scan: its beta and its count to every replica
-      bj = s_bj[lane];
-      nfail = s_nf;
-    }
-    __syncthreads();                     // (s_bj, s_nf are rewritten by the next scan)
+    const bool was_solo = spec_on;
+    if (was_solo) nfail = s_nf[k & 1];   // wavefront 0's scan: its count to every wavefront
     // a chain pressed against its bounds gains nothing from speculating: move by move then, look again every 8th scan
     spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
+    if (was_solo && !spec_on && wave != 0) bj = s_bj[k & 1][lane];   // the replicas are needed again: wavefront 0's beta
     if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
   }
   if (wave == 0 && row) a.beta_out[lane] = bj;
