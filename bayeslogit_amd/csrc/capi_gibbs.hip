@@ -216,6 +216,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
                         st[19], st[16], st[17], st[18]);
     if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu  (segments of 64: exact moves %llu, passes taken again %llu)\n", st[20], st[21], st[22], st[20], st[21]);
     if (st[11]) fprintf(stderr, "  random inputs generated (waves 1-3) after %.1f us\n", (st[11] - st[0]) / 100.0);
+    if (st[14]) fprintf(stderr, "  scans as one segment on wavefront 0: %llu shader cycles inside them\n", st[14]);
     if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }
   return BL_OK;

@@ -1069,7 +1069,9 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     if (spec_on) {
       // the scan as one speculative segment on wavefront 0 (the others stage the next records and wait)
       if (wave == 0) {
+        const long long tq0 = a.dbg ? clock64() : 0;
         nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw, s_zk, zz, bj);
+        if (a.dbg && t == 0) a.dbg[14] += (unsigned long long)(clock64() - tq0);
         s_bj[k & 1][lane] = bj;
         if (lane == 0) s_nf[k & 1] = nfail;
       }
