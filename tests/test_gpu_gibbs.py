@@ -717,7 +717,7 @@ def test_call_sequence_streams_are_separate(gpu, oracle):
     assert np.allclose(out["beta"], bo, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("P", [70, 128, 200, 256])
+@pytest.mark.parametrize("P", [65, 70, 127, 128, 129, 191, 193, 200, 255, 256])
 def test_constrained_sweeps_two_kernels_same_bits(gpu, P):
     """The coordinate sweeps of the constrained draw for 64 < P <= 256 (Logit.hpp:368-399) exist as two kernels -- rows
     split over four wavefronts in speculative segments of 64 moves (the default, which hands a chain that is pressed
@@ -729,7 +729,7 @@ def test_constrained_sweeps_two_kernels_same_bits(gpu, P):
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
     X, y, n = synth(8, P, 1)
     problems = [_beta_problem(P, 100 + P)]
-    Xr, yr, nr = synth(4000 * P if P <= 128 else 1500 * P, P, 7, nmax=1)
+    Xr, yr, nr = synth(3000 * P if P <= 128 else 1200 * P, P, 7, nmax=1)      # (every tail length of the last segment: P mod 64, P mod 8)
     bt = np.abs(rng.normal(size=P)) * 0.4 + 0.3
     yr = (rng.random(Xr.shape[0]) < 1.0 / (1.0 + np.exp(-(Xr @ bt)))).astype(np.float64)
     w = rng.gamma(2.0, 0.12, Xr.shape[0])
