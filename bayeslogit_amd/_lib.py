@@ -1,4 +1,4 @@
-"""ctypes binding of libbayeslogit_hip.so (the C ABI of include/bayeslogit_hip.h).
+"""ctypes binding of libbayeslogit_hip.so (the C ABI of include/bayeslogit_hip.h and of the diagnostic header include/bayeslogit_hip_diag.h).
 
 There is no CPU implementation behind this package: if the HIP library is not
 built, or no GPU is present when a compute entry point is called, the call
@@ -19,7 +19,7 @@ c_u32 = C.c_uint32
 c_i64 = C.c_int64
 c_vp = C.c_void_p
 
-# every symbol include/bayeslogit_hip.h declares: name -> (restype, argtypes)
+# every symbol include/bayeslogit_hip.h and include/bayeslogit_hip_diag.h declare: name -> (restype, argtypes)
 SIGNATURES = {
     "bl_last_error": (C.c_char_p, []),
     "bl_last_sampler_flags": (C.c_int, []),
@@ -53,6 +53,7 @@ SIGNATURES = {
     "bl_rpg_gamma_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),
     "bl_diag_mfma_f64_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
     "bl_diag_mfma_f64_small_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
+    "bl_diag_sp_vlk_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "bl_fill_unif_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),
     "bl_fill_norm_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),
     "bl_fill_shape_dev": (C.c_int, [c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),

@@ -24,7 +24,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "bayeslogit_hip.h"))
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     return hdrs
 
 

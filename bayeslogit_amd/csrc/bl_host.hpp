@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/bayeslogit_hip.h"
+#include "../../include/bayeslogit_hip_diag.h"
 
 namespace blh {
 

@@ -23,7 +23,37 @@ int launch_rpg_tasks(bool sp, double* x, const double* h, const double* z, int64
 
 }  // namespace blh
 
+namespace bl {
+// diagnostic: the fitted saddle-point inversion (sp_vlk: v(x), -log cos_rt v, log K2 -- what the attempt body evaluates where
+// the reference runs InvertY.cpp:57-99's table bracket + Newton solve), table staged in LDS exactly as k_rpg_tasks<SpPolicy> does
+__global__ __launch_bounds__(256) void k_diag_sp_vlk(double* __restrict__ out, const double* __restrict__ x, int64_t num)
+{
+  __shared__ double sVt[kVtabDoubles];
+  const double* src = &kVtab[0][0][0];
+  for (int i = threadIdx.x; i < kVtabDoubles; i += 256) sVt[i] = src[i];
+  __syncthreads();
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < num; i0 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i0 + threadIdx.x;
+    const double xx = i < num ? x[i] : 1.0;
+    double v, L, lK2;
+    sp_vlk(sVt, xx, log(xx), v, L, lK2);
+    if (i < num) { out[3 * i] = v; out[3 * i + 1] = L; out[3 * i + 2] = lK2; }
+  }
+}
+}  // namespace bl
+
 extern "C" {
+
+int bl_diag_sp_vlk_dev(double* out3, const double* x, int64_t num, void* stream)
+{
+  if (!blh::ensure_device()) return BL_ERR_NO_DEVICE;
+  if (num < 0 || (num > 0 && (!out3 || !x))) { blh::set_error("null pointer or negative length"); return BL_ERR_ARG; }
+  if (num == 0) return BL_OK;
+  const int64_t blocks = (num + 255) / 256;
+  hipLaunchKernelGGL(bl::k_diag_sp_vlk, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, out3, x, num);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
 
 int bl_rpg_alt_dev(double* x, const double* h, const double* z, int64_t num, uint64_t seed, uint32_t epoch,
                    uint64_t idx0, void* stream)

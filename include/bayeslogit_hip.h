@@ -125,27 +125,6 @@ int bl_fill_norm_dev(double *out, int64_t num, double mean, double sd,
 /* h[i] = 1 + (Philox word mod kmax) : integer shapes 1..kmax as doubles */
 int bl_fill_shape_dev(double *out, int64_t num, int kmax,
                       uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);
-/* diagnostic (bench.py's roofline): one launch of a register-only loop of `iters` x 10 independent
- * v_mfma_f64_16x16x4_f64 per wave, `waves_per_simd` (1..8) waves on every SIMD; *flops = the flops that launch
- * performs (the caller times it with events on `stream`).  work: >= CUs * waves_per_simd * 256 doubles. */
-int bl_diag_mfma_f64_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
-                         void *stream);
-/* the same loop on v_mfma_f64_4x4x4_4b_f64 (512 flops), the instruction the X' Omega X kernels for P >= 64 are built on */
-int bl_diag_mfma_f64_small_dev(double *work, int64_t work_doubles, int waves_per_simd, int iters, double *flops,
-                               void *stream);
-/* The Gibbs sweep over a rank's rows (Logit.hpp:283-301,431: psi = X beta, omega ~ PG(n, psi), X' Omega X) reads X
- * once when P = 64 (single_pass = 1, the default; env BL_SWEEP_SINGLE_PASS) or in two streaming passes
- * (single_pass = 0; every other P).  Same omega bit for bit; X' Omega X in another, equally fixed, summation order.
- * A bl_gibbs handle goes back to the two passes by itself when more than a fifth of its rows leave the single pass's fast
- * path (|psi|/2 >= 1/t, n != 1: rare-event data), looked at after its 8th and 64th sweep: a function of data and chain only.
- * bl_diag_sweep_deferred: rows the single-pass kernel handed to the full sampler since the last call (a sync). */
-void bl_set_sweep_mode(int single_pass);
-int  bl_diag_sweep_deferred(uint64_t *rows);
-/* The coordinate sweeps of the constrained beta draw (Logit.hpp:368-399) for 64 < P <= 256 exist twice, for comparison:
- * row_split = 1 (default; env BL_BETA_SPLIT) = rows split over four wavefronts, speculative segments of 64 moves, with a
- * chain that is pressed against its bounds handed to the other kernel by itself; 0 = all rows on one wavefront, move by
- * move.  Same beta bit for bit. */
-void bl_diag_beta_sweeps(int row_split);
 /* y[i] ~ Bernoulli(sigmoid(x_i . beta)) for a P x N column-major tX */
 int bl_fill_logit_y_dev(double *y, const double *tX, const double *beta, int64_t N, int P,
                         uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);

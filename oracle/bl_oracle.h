@@ -10,9 +10,15 @@
  * reference checkout, e.g. Code/C/PolyaGamma.cpp:151-202).
  *
  * Pinning status (see oracle/README.md):
- *   - The reference's C path needs two third-party headers that are not in
- *     its tree (jwindle/RNG "RNG.hpp", jwindle/Matrix; INSTALL:14-33), so it
- *     is UNBUILDABLE here and no oracle/_ref exists.
+ *   - The reference's samplers and Gibbs driver need two third-party headers
+ *     that are not in its tree (jwindle/RNG "RNG.hpp", jwindle/Matrix;
+ *     INSTALL:14-33): UNBUILDABLE here without stand-ins, which we do not
+ *     write.  The one file of the path that needs neither, Code/C/InvertY.cpp
+ *     (y_eval, ydy_eval, fdf_eval, v_eval: the saddle-point sampler's
+ *     inversion), is compiled UNCHANGED into oracle/_ref/libinverty_ref.so
+ *     (`make -C oracle ref`); its outputs on a grid are the golden file
+ *     tests/golden/inverty_ref.json, and bl_y_eval / bl_ydy_eval / bl_fdf_eval
+ *     / bl_v_eval equal it bit for bit (tests/test_inverty_ref.py).
  *   - The reference holds no golden vectors (no test asserts anything).  The
  *     oracle is pinned by what the reference's own tests/data do hold:
  *       * Code/R/t1to4.txt == trunc_schedule (data file, tests/golden/),
@@ -96,6 +102,8 @@ double bl_alt_draw(double h, double z, bl_rng *r);
 extern const double bl_ygrid[81];
 extern const double bl_vgrid[81];
 double bl_y_eval(double v);
+void bl_ydy_eval(double v, double *yp, double *dyp);
+void bl_fdf_eval(double v, double y, double *fp, double *dfp);
 double bl_v_eval(double y);
 double bl_sp_y_func(double v);
 double bl_sp_approx(double x, double n, double z);

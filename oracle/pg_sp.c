@@ -30,7 +30,7 @@ double bl_y_eval(double v)
 }
 
 /* ydy_eval(v, &y, &dy) -- InvertY.cpp:23-35 */
-static void ydy_eval(double v, double *yp, double *dyp)
+void bl_ydy_eval(double v, double *yp, double *dyp)
 {
   double y = bl_y_eval(v);
   *yp = y;
@@ -38,6 +38,13 @@ static void ydy_eval(double v, double *yp, double *dyp)
     *dyp = 0.5 * (y * y + (1 - y) / v);
   else
     *dyp = 0.5 * (y * y - H5_ONE_THIRD - H5_TWO_FIFTEENTHS * v);
+}
+
+/* fdf_eval(v, &y, &f, &df): f = y(v) - y -- InvertY.cpp:43-48 */
+void bl_fdf_eval(double v, double y, double *fp, double *dfp)
+{
+  bl_ydy_eval(v, fp, dfp);
+  *fp -= y;
 }
 
 /* v_eval(y, tol=1e-9, max_iter=1000) -- InvertY.cpp:57-99 */
@@ -66,8 +73,7 @@ double bl_v_eval(double y)
   while (diff > tol && iter < max_iter) {
     iter++;
     vold = vnew;
-    ydy_eval(vold, &f0, &f1);       /* fdf_eval: f = y(v) - y, InvertY.cpp:43-48 */
-    f0 -= y;
+    bl_fdf_eval(vold, y, &f0, &f1);
     vnew = vold - f0 / f1;
     vnew = vnew > vh ? vh : vnew;
     vnew = vnew < vl ? vl : vnew;

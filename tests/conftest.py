@@ -12,12 +12,16 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the checker is compiled here, before any test can have touched the GPU (oracle_lib.lib() itself never builds)
+    import oracle_lib
+    if not os.path.exists(os.path.join(oracle_lib.ORACLE_DIR, "liboracle.so")):
+        oracle_lib.build()
 
 
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
-    oracle_lib.lib()          # builds liboracle.so on first use
+    oracle_lib.lib()          # raises if liboracle.so is missing (built at configure time / by build())
     return oracle_lib
 
 

@@ -28,6 +28,9 @@ class BlRng(C.Structure):
 
 
 def build():
+    """Compile liboracle.so.  Called by tests/conftest.py at configure time (before any test has touched the GPU)
+    and by __graft_entry__.build(); never from lib(): a process that has initialised the GPU (bench.py, smoke())
+    must not start other programs on this pool."""
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
 
 
@@ -37,7 +40,8 @@ def lib():
         return _LIB
     path = os.path.join(ORACLE_DIR, "liboracle.so")
     if not os.path.exists(path):
-        build()
+        raise RuntimeError(f"{path} is missing: build it first with `make -C oracle liboracle.so` "
+                           "(__graft_entry__.build() does); lib() does not compile anything")
     L = C.CDLL(path)
     rp = C.POINTER(BlRng)
 
@@ -71,6 +75,8 @@ def lib():
     sig("bl_alt_w_left", c_d, c_d, c_d, c_d)
     sig("bl_alt_w_right", c_d, c_d, c_d, c_d)
     sig("bl_y_eval", c_d, c_d)
+    sig("bl_ydy_eval", None, c_d, c_dp, c_dp)
+    sig("bl_fdf_eval", None, c_d, c_d, c_dp, c_dp)
     sig("bl_v_eval", c_d, c_d)
     sig("bl_sp_y_func", c_d, c_d)
     sig("bl_sp_approx", c_d, c_d, c_d, c_d)

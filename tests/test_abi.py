@@ -1,5 +1,6 @@
-"""The C-ABI shared library loads and exports every symbol include/bayeslogit_hip.h declares.
-No compute call is made here (this file runs without a GPU)."""
+"""The C-ABI shared library loads and exports every symbol include/*.h declares (bayeslogit_hip.h: the drop-in
+boundary and its device-resident form; bayeslogit_hip_diag.h: diagnostics).  No compute call is made here (this
+file runs without a GPU)."""
 import os
 import re
 import subprocess
@@ -8,11 +9,11 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-HEADER = os.path.join(ROOT, "include", "bayeslogit_hip.h")
+HEADERS = [os.path.join(ROOT, "include", f) for f in ("bayeslogit_hip.h", "bayeslogit_hip_diag.h")]
 
 
-def declared_symbols():
-    src = open(HEADER).read()
+def declared_symbols(headers=HEADERS):
+    src = "\n".join(open(h).read() for h in headers)
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src)
     skip = {"defined", "sizeof"}
@@ -23,7 +24,9 @@ def test_header_declares_reference_table():
     """The drop-in table is exactly Code/C/LogitWrapper.h:23-64 (10 entry points)."""
     ref = {"rpg_gamma", "rpg_devroye", "rpg_alt", "rpg_sp", "rpg_hybrid", "gibbs", "EM", "combine", "mult_gibbs",
            "mult_combine"}
-    assert ref <= set(declared_symbols())
+    assert ref <= set(declared_symbols(HEADERS[:1]))
+    # diagnostics live in their own header: the boundary header declares none
+    assert not [n for n in declared_symbols(HEADERS[:1]) if n.startswith("bl_diag_")]
 
 
 def test_library_exports_every_declared_symbol(hiplib):
