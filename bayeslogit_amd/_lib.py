@@ -65,6 +65,7 @@ SIGNATURES = {
     "bl_gibbs_set_beta": (C.c_int, [c_vp, c_dp]),
     "bl_gibbs_set_bp_local": (C.c_int, [c_vp]),
     "bl_gibbs_finish_bp": (C.c_int, [c_vp]),
+    "bl_gibbs_chain_start": (C.c_int, [c_vp]),
     "bl_gibbs_sweep_local": (C.c_int, [c_vp, c_u32, c_vp]),
     "bl_gibbs_draw_beta": (C.c_int, [c_vp, c_u32, C.c_int]),
     "bl_gibbs_em_local": (C.c_int, [c_vp]),

@@ -238,7 +238,10 @@ BL_HD bool alt_attempt(AltLane& s, const AltPar& p, double u1, double u2, int& s
 // blk0 on: group A from block 0, group B from block 2^31, so the two groups of an observation can be drawn
 // by different lanes at different times and x = sumA + sumB (one fp addition: commutative) is the same.
 constexpr uint32_t kAltBlkGroupB = 0x80000000u;
-constexpr uint32_t kAltBlkCap = 4000000u;      // blocks per task (the reference's inner loops are uncapped)
+#ifndef BL_ALT_BLK_CAP
+#define BL_ALT_BLK_CAP 4000000u
+#endif
+constexpr uint32_t kAltBlkCap = BL_ALT_BLK_CAP;   // blocks per abridged DRAW (the reference's inner loops are uncapped); not per task
 constexpr int kAltMaxTrials = 10000;           // :142
 
 struct AltTask {
@@ -288,6 +291,7 @@ BL_HD bool alt_task_step(AltTask& T, uint32_t epoch, uint32_t k0, uint32_t k1, i
   if (got) {
     T.sum += val;
     T.trials = 0;
+    T.blk_end = T.blk + kAltBlkCap;     // the cap counts from the start of each draw: a group of many draws is not cut short
     return --T.nrem <= 0;
   }
   return false;

@@ -82,7 +82,9 @@ struct BetaArgs {
   double* work;            // beta_work_doubles(P) doubles of scratch
   uint64_t seed;
   uint32_t epoch;
-  int* status;             // BL_ERR_NOT_PD flag word (host-visible int, device memory)
+  int* status;             // BL_ERR_NOT_PD flag word (host-visible int, device memory): reporting only
+  int* dead;               // this chain's own sticky flag (device int, zero while the chain is alive): set with ST_NOT_PD when a
+                           // factorisation fails; every later beta kernel of THIS chain returns at once.  Never null.
   unsigned long long* dbg = nullptr;   // optional: 8 phase stamps (100 MHz wall clock), development aid
 };
 size_t beta_work_doubles(int P);

@@ -24,12 +24,12 @@ namespace bl {
 // A lane's in-flight observation.  Self-contained: once an observation has been started nothing of
 // the list it came from (index list, staged mass, z) is read again, so the state survives the caller
 // rebuilding those for its next chunk.
-constexpr uint32_t kPg1BlkCap = 4000000u;   // Philox blocks per observation
-
+// (kPg1BlkCap, Philox blocks per PG(1,z) DRAW: bl_pg1_sm.hpp)
 struct Pg1Slot {
   int64_t row = -1;         // index into x[] / global observation offset; -1 = idle
   int nrem = 0;             // PG(1,z) draws still to add (PolyaGamma::draw(int n, ...), :126-140)
   uint32_t c0 = 0, c1 = 0, blk = 0;   // Philox counter words of the observation's stream, next block
+  uint32_t cap = 0;         // first block the draw in progress may not use (blk at its start + kPg1BlkCap)
   double sum = 0.0;
   Pg1Par par{0.0, 1.0, 0.5, 2.0, 2.0};
   Pg1Lane sm{true, 0.0};
@@ -69,6 +69,7 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
         L.c0 = (uint32_t)idx;
         L.c1 = ctr1_of(idx, DOM);
         L.blk = 0;
+        L.cap = kPg1BlkCap;
         L.sum = 0.0;
         L.sm.fresh = true;
       }
@@ -84,9 +85,10 @@ __device__ __forceinline__ void devroye_queue_run(Pg1Slot& L, bool drain, const 
       if (pg1_attempt<true, ZC>(L.sm, L.par, u52(o.x, o.y), u52(o.z, o.w), st_flags)) {
         L.sum += 0.25 * L.sm.X;
         if (--L.nrem == 0) { x[L.row] = L.sum; L.row = -1; }
+        L.cap = L.blk + kPg1BlkCap;          // per draw: an observation's n is not limited by the cap
       }
       // the reference's loops are uncapped (PolyaGamma.cpp:167,181); a lane that never exits would hang its wave
-      if (L.row >= 0 && L.blk > kPg1BlkCap) { st_flags |= ST_ITER_CAP; x[L.row] = L.sum; L.row = -1; }
+      if (L.row >= 0 && L.blk == L.cap) { st_flags |= ST_ITER_CAP; x[L.row] = L.sum; L.row = -1; }
     }
     if (!drain && next >= cnt) break;
   }

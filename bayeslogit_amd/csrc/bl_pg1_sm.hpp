@@ -51,6 +51,13 @@ constexpr double kSmInvSqrt2T = 0.88388347648318440550105545263106;   // 1/sqrt(
 constexpr double kSmLogHalfPi = 0.45158270528945486472619522989488;
 constexpr double kSmRatioMax = 0.006;   // > 3 exp(-pi^2 t) = 0.00542 and > 3 exp(-4/t) = 0.00579
 constexpr double kSmWMin = 0x1.0p-53, kSmWMax = 1.0 - 0x1.0p-53;   // recycled uniforms stay inside (0,1)
+// The reference's loops are uncapped (PolyaGamma.cpp:167,181); a lane that never exits would hang its wave, so ONE PG(1,z)
+// draw may spend at most this many Philox blocks (an attempt fails with probability < 0.3: the cap is a pathology detector,
+// not a limit on n -- the count starts again with every draw of an observation's sum).  Overridable for the host tests.
+#ifndef BL_PG1_BLK_CAP
+#define BL_PG1_BLK_CAP 4000000u
+#endif
+constexpr uint32_t kPg1BlkCap = BL_PG1_BLK_CAP;
 
 struct Pg1Par {      // per observation, from z
   double Z;          // |z|/2
@@ -324,14 +331,16 @@ BL_HD double pg1_draw_n(int n, double z, uint64_t seed, uint64_t idx, uint32_t d
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t c0 = (uint32_t)idx, c1 = ctr1_of(idx, domain);
   double sum = 0.0;
-  for (uint32_t blk = 0; blk < 4000000u; ++blk) {
+  uint32_t cap = kPg1BlkCap;         // first block the current draw may not use
+  for (uint32_t blk = 0; blk != cap; ++blk) {
     const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
     if (pg1_attempt(s, p, u52(o.x, o.y), u52(o.z, o.w), status)) {
       sum += 0.25 * s.X;
       if (--n == 0) return sum;
+      cap = blk + 1u + kPg1BlkCap;   // per draw, not per observation: n is not limited by it
     }
   }
-  status |= 1;
+  status |= 1;                       // a draw ran into the cap: flagged, the sum so far returned
   return sum;
 }
 

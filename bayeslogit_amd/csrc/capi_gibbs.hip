@@ -19,7 +19,8 @@ struct bl_gibbs {
   double* pool = nullptr;   // one allocation, carved below
   double *PP = nullptr, *bP = nullptr, *beta = nullptr, *beta_old = nullptr, *P0 = nullptr, *m0 = nullptr,
          *b0 = nullptr, *partial = nullptr, *colws = nullptr, *wscr = nullptr, *work = nullptr, *dist = nullptr;
-  int draw_sweeps = 0, draw_sweeps_at_check = 0;   // bl_gibbs_sweep_local calls (the single-pass fall-back policy)
+  int* dead = nullptr;      // the chain's sticky "a Cholesky factorisation failed" word (in the pool; BetaArgs::dead)
+  int draw_sweeps = 0, draw_sweeps_at_check = 0;   // bl_gibbs_sweep_local calls since the chain started (the single-pass fall-back policy)
 };
 
 namespace {
@@ -80,6 +81,7 @@ int bl_gibbs_create(bl_gibbs** out, int64_t N_local, int P, uint64_t idx0, uint6
   h->m0 = p; p += P;
   h->b0 = p; p += P;
   h->dist = p; p += 8;
+  h->dead = (int*)(h->dist + 4);        // zeroed with the pool
   h->partial = p; p += h->plan.partial_doubles;
   h->colws = p; p += colws;
   h->wscr = p; p += wscr;
@@ -154,6 +156,23 @@ int bl_gibbs_finish_bp(bl_gibbs* h)
   return BL_OK;
 }
 
+// A chain starts: the handle forgets what an earlier chain left behind -- the count of sweeps and of deferred rows behind
+// the single-pass fall-back (so the decision is a function of THIS chain's data and draws only: the same seed on the same
+// handle gives the same bits twice) and the dead-chain flag.  bl_gibbs_run / bl_gibbs_run_stream call it; a driver of the
+// step API (bl_gibbs_sweep_local / bl_gibbs_draw_beta) calls it where its chain begins.
+int bl_gibbs_chain_start(bl_gibbs* h)
+{
+  if (int rc = valid(h)) return rc;
+  h->draw_sweeps = 0;
+  h->draw_sweeps_at_check = 0;
+  h->plan.single_pass = -1;
+  BL_HIP_TRY(hipMemsetAsync(h->dead, 0, sizeof(int), h->stream));
+  if (h->P == 64 && h->N > 0)
+    BL_HIP_TRY(hipMemsetAsync(blk::sweep_once64_deferred_counter(h->partial, h->plan.nblocks, h->N), 0,
+                              sizeof(unsigned long long), h->stream));
+  return BL_OK;
+}
+
 int bl_gibbs_sweep_local(bl_gibbs* h, uint32_t sweep, double* w_out)
 {
   if (int rc = valid(h)) return rc;
@@ -193,6 +212,7 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
   a.seed = h->seed;
   a.epoch = sweep;
   a.status = blh::status_word(h->stream);
+  a.dead = h->dead;
   static const bool dbg = getenv("BL_BETA_DEBUG") != nullptr;   // development aid: phase timing of the beta stage
   static unsigned long long* dbuf = nullptr;
   if (dbg) {
@@ -246,6 +266,7 @@ int bl_gibbs_em_solve(bl_gibbs* h, double* dist_host)
   a.seed = h->seed;
   a.epoch = 0;
   a.status = blh::status_word(h->stream);
+  a.dead = h->dead;
   blk::launch_beta(a, blk::B_SOLVE, h->stream);
   blk::launch_maxabsdiff(h->beta, h->beta_old, h->P, h->dist, h->stream);
   BL_HIP_TRY(hipGetLastError());
@@ -280,7 +301,8 @@ int bl_gibbs_run(bl_gibbs* h, int samp, int burn, int constrain, double* beta_ou
   const int P = h->P;
   double* hist = nullptr;
   BL_HIP_TRY(hipMalloc((void**)&hist, sizeof(double) * (size_t)P * samp));
-  int rc = bl_gibbs_set_bp_local(h);
+  int rc = bl_gibbs_chain_start(h);
+  if (rc == BL_OK) rc = bl_gibbs_set_bp_local(h);
   if (rc == BL_OK) rc = bl_gibbs_finish_bp(h);
   hipError_t e = hipMemsetAsync(h->beta, 0, sizeof(double) * P, h->stream);   // chain starts at beta = 0
   uint32_t sweep = 0;
@@ -350,7 +372,8 @@ int bl_gibbs_run_stream(bl_gibbs* h, int samp, int burn, int constrain, int thin
     e = hipMemsetAsync(stats->w_mean_dev, 0, sizeof(double) * N, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(stats->w_var_dev, 0, sizeof(double) * N, h->stream);
   }
-  int rc = e == hipSuccess ? bl_gibbs_set_bp_local(h) : BL_ERR_HIP;
+  int rc = e == hipSuccess ? bl_gibbs_chain_start(h) : BL_ERR_HIP;
+  if (rc == BL_OK) rc = bl_gibbs_set_bp_local(h);
   if (rc == BL_OK) rc = bl_gibbs_finish_bp(h);
   if (rc == BL_OK && hipMemsetAsync(h->beta, 0, sizeof(double) * P, h->stream) != hipSuccess) rc = BL_ERR_HIP;
   uint32_t sweep = 0;
@@ -660,6 +683,7 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
       a.seed = seed;
       a.epoch = epoch;
       a.status = blh::status_word(s);
+      a.dead = h->dead;
       blk::launch_beta(a, blk::B_FROM_LIK, s);
       blk::launch_xbeta(dX.p, bj, n, p, dXB.p + (size_t)j * n, s);                 // XB_j = X beta_j
     }

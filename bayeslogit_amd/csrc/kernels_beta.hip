@@ -284,9 +284,9 @@ __device__ void constrained_wide_reciprocals(const blk::BetaArgs& a, const doubl
 __global__ __launch_bounds__(kDenseThreads) void k_beta_factor(blk::BetaArgs a, int mode)
 {
   __shared__ DenseLds L;
-  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // a Cholesky factorisation failed earlier in this chain (the chain's own flag, BetaArgs::dead: another handle's failure does not stop this one):
   // the chain is dead, and the stages behind this one would read a workspace nobody prepared
-  if (*a.status & ST_NOT_PD) return;
+  if (*a.dead != 0) return;
   const int P = a.P, t = threadIdx.x;
   double* A = a.work;                      // PP, then U
   double* mP = a.work + 2 * (size_t)P * P; // posterior mean
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_beta_factor(blk::BetaArgs a, 
   __syncthreads();
   const View U{A, 1, P};
   if (!wg_chol(L, U, P)) {
-    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    if (t == 0) (atomicOr(a.status, ST_NOT_PD), atomicOr(a.dead, 1));
     return;
   }
   if (mode != blk::B_SOLVE && mode != blk::B_MVN) return;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_beta_factor(blk::BetaArgs a, 
 __global__ __launch_bounds__(kDenseThreads) void k_beta_inverse(blk::BetaArgs a, int nc, int cpw)
 {
   __shared__ DenseLds L;
-  if (*a.status & ST_NOT_PD) return;
+  if (*a.dead != 0) return;
   const int P = a.P, t = threadIdx.x;
   double* A = a.work;
   double* S = a.work + (size_t)P * P;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_beta_finish(blk::BetaArgs a, 
 {
   __shared__ DenseLds L;
   extern __shared__ double lds[];          // P > 256 constrained: beta, z (P each), perm
-  if (*a.status & ST_NOT_PD) return;
+  if (*a.dead != 0) return;
   const int P = a.P, t = threadIdx.x;
   double* A = a.work;                      // U
   double* S = a.work + (size_t)P * P;      // PP^{-1}, then L
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_beta_finish(blk::BetaArgs a, 
     __syncthreads();
   }
   if (!wg_chol(L, View{S, P, 1}, P)) {     // L = chol(S,'L'), in place
-    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    if (t == 0) (atomicOr(a.status, ST_NOT_PD), atomicOr(a.dead, 1));
     return;
   }
   for (int e = t; e < P * P; e += kDenseThreads) {
@@ -830,9 +830,9 @@ __device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lan
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];
-  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // a Cholesky factorisation failed earlier in this chain (the chain's own flag, BetaArgs::dead: another handle's failure does not stop this one):
   // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
-  if (*a.status & ST_NOT_PD) return;
+  if (*a.dead != 0) return;
   const int P = a.P, t = threadIdx.x, ld = P + 1;
   double* A = lds;                       // PP -> U
   double* S = A + P * ld;                // PP^{-1} -> L
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     if (t < 64) {
       const int lane = t;
       if (!w_chol_reg<false>(A, P, ld, lane, s_piv)) {
-        if (lane == 0) atomicOr(a.status, ST_NOT_PD);
+        if (lane == 0) (atomicOr(a.status, ST_NOT_PD), atomicOr(a.dead, 1));
       } else {
         double m = lane < P ? a.bP[lane] : 0.0;
         m = w_solve_Ut_vec(A, m, P, ld, lane);
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
   __syncthreads();
   if (bad) {
-    if (t == 0) atomicOr(a.status, ST_NOT_PD);
+    if (t == 0) (atomicOr(a.status, ST_NOT_PD), atomicOr(a.dead, 1));
     return;
   }
   if (mode != blk::B_CONSTRAINED) return;
@@ -1197,9 +1197,9 @@ template <int RPL>
 __global__ __launch_bounds__(kBlock) void k_beta_sweeps(blk::BetaArgs a, bool paired)
 {
   extern __shared__ double lds[];
-  // a Cholesky factorisation failed earlier in this chain (ST_NOT_PD is sticky until the host collects the status word):
+  // a Cholesky factorisation failed earlier in this chain (the chain's own flag, BetaArgs::dead: another handle's failure does not stop this one):
   // the chain is dead, and for 64 < P <= 256 k_beta has not prepared the workspace k_beta_sweeps reads
-  if (*a.status & ST_NOT_PD) return;
+  if (*a.dead != 0) return;
   const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;
   // paired: launched behind k_beta_sweeps_run (launch_beta); the chain's mode word says which of the two takes this draw
   uint32_t* mode = paired ? beta_mode_word(a) : nullptr;
@@ -1804,7 +1804,7 @@ template <int NQ>
 __global__ __launch_bounds__(kBlock) void k_beta_sweeps_run(blk::BetaArgs a)
 {
   extern __shared__ double lds[];
-  if (*a.status & ST_NOT_PD) return;       // see k_beta
+  if (*a.dead != 0) return;       // see k_beta
   uint32_t* mode = beta_mode_word(a);
   if (mode[0] != 0u) return;               // a chain pressed against its bounds: k_beta_sweeps, launched behind, takes the draw
   const int P = a.P, t = threadIdx.x, nthr = (int)blockDim.x;

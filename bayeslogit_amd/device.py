@@ -196,6 +196,10 @@ class GibbsShard:
     def finish_bp(self):
         _lib.check(_lib.lib().bl_gibbs_finish_bp(self.h), "bl_gibbs_finish_bp")
 
+    def chain_start(self):
+        """A chain driven sweep by sweep begins here (bl_gibbs_chain_start)."""
+        _lib.check(_lib.lib().bl_gibbs_chain_start(self.h), "bl_gibbs_chain_start")
+
     def sweep_local(self, sweep, w_out=None):
         _lib.check(_lib.lib().bl_gibbs_sweep_local(self.h, sweep, _ptr(w_out)), "bl_gibbs_sweep_local")
 

@@ -47,6 +47,8 @@ class DistGibbs:
     def setup(self, m0, P0, beta0=None):
         s = self.shard
         s.set_prior(m0, P0)
+        if hasattr(s, "chain_start"):
+            s.chain_start()
         s.set_bp_local()
         self._all_reduce(s.bp())
         s.finish_bp()

@@ -2,7 +2,10 @@
 """bench.py -- headline benchmark of the Polya-Gamma hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N: WORLD_SIZE is then set)
+  or bench.py does: a plain `python bench.py --gpus N` starts that same command as a CHILD process before this
+  process has made any GPU call, passes its output through and exits with its code (launch_ranks below).
 
 Primary metric (BASELINE.json): PG draws/sec (millions) on config C2 --
 1e8 PG(1, z) draws per GPU, z ~ Unif(0,4) generated on the device.  A "step" is one
@@ -16,6 +19,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,7 +51,10 @@ def parse():
     ap.add_argument("--gibbs-chain", type=int, default=1000,
                     help="C4 only: also run a chain of 100 burn-in + this many sampling sweeps (SURVEY 8d: posterior "
                          "mean and sd of beta, sweeps/s over the sampling phase); 0 = skip")
-    ap.add_argument("--c5", action="store_true", help="also time one GPU's shard of config C5 (12.5e6 x 256 per rank)")
+    ap.add_argument("--c5", action="store_true", help="(default now; kept so that older command lines still parse)")
+    ap.add_argument("--no-c5", action="store_true", help="skip config C5 (N = 1e8, P = 256 over 8 GPUs: 12.5e6 x 256 rows, "
+                                                         "25.6 GB, per rank -- the full problem at --gpus 8)")
+    ap.add_argument("--c5-rows", type=int, default=12_500_000, help="rows per rank of the C5 leg")
     ap.add_argument("--c5-sweeps", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mixed", action="store_true", help="skip config C3 (mixed shapes b in 1..50 through rpg_hybrid)")
@@ -60,6 +68,31 @@ def parse():
     ap.add_argument("--cpu-gibbs-n", type=int, default=1_000_000, help="rows of the timed CPU Gibbs sample (10 sweeps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
     return ap.parse_args()
+
+
+def launcher_cmd(argv, nproc, port):
+    """The command a plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts: the driver's own launch line
+    (one rank per GPU, rendezvous on 127.0.0.1) with bench.py's arguments passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(a, argv):
+    """N > 1 without a launcher: start the ranks as fresh children and return their exit code.  This process never
+    touches the GPU (counting devices does not initialise it on this image; a process that HAS initialised the GPU must not
+    start other programs on this pool), it only relays: rank 0 of the children prints the JSON line."""
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and ndev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} over RCCL needs {a.gpus} GPUs, {ndev} visible "
+              "(--backend gloo rehearses the N > 1 path with the ranks sharing the GPUs there are)", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.call(launcher_cmd(argv, a.gpus, port), env=env)
 
 
 def barrier_sync(world):
@@ -123,6 +156,23 @@ def pmc_traffic(kernel):
         return e.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
     except (OSError, ValueError):
         return None, None
+
+
+def time_allreduce(numel, world, dev, reps=50):
+    """The sweep's one exchange on its own: all-reduce(sum) of `numel` doubles (P*P), microseconds per call, max over
+    ranks (barrier + synchronize on both sides; 5 untimed calls first)."""
+    if world == 1:
+        return 0.0
+    t = torch.zeros(numel, dtype=torch.float64, device=dev)
+    for _ in range(5):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return max_over_ranks(dt, world, dev) / reps * 1e6
 
 
 def cpu_baseline(draws_sample, ncores):
@@ -268,24 +318,26 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
     res = {}
     for name, con in (("constrained", 1), ("unconstrained", 0)):
         sw = [0]
-        ks, kb = [], []
+        ks, ka, kb = [], [], []
 
         def gstep():
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
             e0.record()
             shard.sweep_local(sw[0], None)
             e1.record()
             drv._all_reduce(shard.pp())
-            shard.draw_beta(sw[0], con)
             e2.record()
+            shard.draw_beta(sw[0], con)
+            e3.record()
             ks.append((e0, e1))
-            kb.append((e1, e2))
+            ka.append((e1, e2))
+            kb.append((e2, e3))
             sw[0] += 1
 
         shard.set_beta(np.zeros(P))
         for _ in range(3):
             gstep()
-        ks.clear(), kb.clear()
+        ks.clear(), ka.clear(), kb.clear()
         barrier_sync(world)
         t0 = time.perf_counter()
         for _ in range(sweeps):
@@ -293,9 +345,16 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         barrier_sync(world)
         gw = max_over_ranks(time.perf_counter() - t0, world, dev)
         sweep_ms = float(np.mean([p.elapsed_time(q) for p, q in ks]))
+        ar_ms = float(np.mean([p.elapsed_time(q) for p, q in ka]))
         beta_ms = float(np.mean([p.elapsed_time(q) for p, q in kb]))
         res[name] = {"sweeps_per_s": sweeps / gw, "ms_per_sweep": gw / sweeps * 1e3,
-                     "sweep_kernel_ms": sweep_ms, "allreduce_plus_beta_ms": beta_ms}
+                     "sweep_kernel_ms": sweep_ms, "allreduce_in_sweep_ms": ar_ms, "beta_stage_ms": beta_ms,
+                     "allreduce_plus_beta_ms": ar_ms + beta_ms}
+    exchange = {"allreduce_us": time_allreduce(P * P, world, dev), "bytes": 8 * P * P, "world_size": world,
+                "backend": (dist.get_backend() if world > 1 else None),
+                "note": "the sweep's only exchange: all-reduce(sum) of the P x P fp64 partial X'Omega X, timed alone (50 calls "
+                        "between barriers, max over ranks); allreduce_in_sweep_ms is the same call inside the sweep, events "
+                        "on the compute stream, so it includes waiting for the slowest rank's sweep kernels"}
     D.sync_status()
     chain_out = None
     if chain > 0:
@@ -391,6 +450,7 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         "beta_draw": "constrained = the reference's active draw (Logit.hpp:322-400); "
                      "unconstrained = Logit.hpp:291-320",
         **res,
+        "exchange": exchange,
         "roofline": roof,
         "chain": chain_out,
     }
@@ -401,6 +461,8 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))          # before anything below touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -413,8 +475,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.backend)
-    elif a.gpus > 1:
-        print("bench.py: --gpus > 1 needs torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
 
     from bayeslogit_amd import _lib
@@ -524,8 +586,10 @@ def main():
     if not a.no_gibbs and rank == 0 and world == 1 and a.mlogit_n > 0:
         out["gibbs"]["mlogit"] = mlogit_bench(a.mlogit_n)
     # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
-    if a.c5:
-        out["gibbs_c5"] = gibbs_bench(12_500_000 * world, 256, a.c5_sweeps, "C5 shard", rank, world, dev, D,
+    if not a.no_c5:
+        tag5 = "C5" if (world == 8 and a.c5_rows == 12_500_000) else \
+               f"C5 shard ({a.c5_rows} rows per rank; the full N = 1e8 problem is 8 ranks x 12.5e6)"
+        out["gibbs_c5"] = gibbs_bench(a.c5_rows * world, 256, a.c5_sweeps, tag5, rank, world, dev, D,
                                       DistGibbs, shard_range)
 
     # ---------------------------------------------------------------- CPU baseline

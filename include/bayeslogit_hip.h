@@ -150,6 +150,10 @@ int  bl_gibbs_set_prior(bl_gibbs *h, const double *m0_host, const double *P0_hos
 int  bl_gibbs_set_beta(bl_gibbs *h, const double *beta_host);
 int  bl_gibbs_set_bp_local(bl_gibbs *h);
 int  bl_gibbs_finish_bp(bl_gibbs *h);
+/* where a chain driven through the step API begins (bl_gibbs_run / bl_gibbs_run_stream call it themselves): the handle
+ * forgets the previous chain's sweep count, deferred-row count (the P = 64 single-pass fall-back decision) and failed-
+ * Cholesky flag, so the same seed on the same handle reproduces the same bits */
+int  bl_gibbs_chain_start(bl_gibbs *h);
 int  bl_gibbs_sweep_local(bl_gibbs *h, uint32_t sweep, double *w_out /* device, N_local, or NULL */);
 int  bl_gibbs_draw_beta(bl_gibbs *h, uint32_t sweep, int constrain);
 /* EM pieces on the same handle (Logit.hpp:488-554): deterministic omega, then solve */

@@ -25,7 +25,7 @@ int bl_diag_mfma_f64_small_dev(double *work, int64_t work_doubles, int waves_per
  * once when P = 64 (single_pass = 1, the default; env BL_SWEEP_SINGLE_PASS) or in two streaming passes
  * (single_pass = 0; every other P).  Same omega bit for bit; X' Omega X in another, equally fixed, summation order.
  * A bl_gibbs handle goes back to the two passes by itself when more than a fifth of its rows leave the single pass's fast
- * path (|psi|/2 >= 1/t, n != 1: rare-event data), looked at after its 8th and 64th sweep: a function of data and chain only.
+ * path (|psi|/2 >= 1/t, n != 1: rare-event data), looked at after the 8th and 64th sweep of a chain (bl_gibbs_chain_start): a function of data and chain only.
  * bl_diag_sweep_deferred: rows the single-pass kernel handed to the full sampler since the last call (a sync). */
 void bl_set_sweep_mode(int single_pass);
 int  bl_diag_sweep_deferred(uint64_t *rows);

@@ -52,16 +52,63 @@ def test_roofline_and_cpu_baseline_objects():
     assert ch["burn"] == 100 and ch["samp"] == 1000 and ch["max_abs_z"] < 5.0       # posterior means near the truth
 
 
-def test_bench_defaults_are_one_gpu_and_short():
+def _bench_module(args):
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     m = importlib.util.module_from_spec(spec)
     argv = sys.argv
     try:
-        sys.argv = ["bench.py"]
+        sys.argv = ["bench.py"] + list(args)
         spec.loader.exec_module(m)
         a = m.parse()
     finally:
         sys.argv = argv
+    return m, a
+
+
+def test_launcher_starts_the_ranks_as_children_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE): main() must hand over to torch.distributed.run -- the
+    driver's own launch line, bench.py's arguments passed through -- as a CHILD process, before this process initialises
+    the GPU, and exit with the child's code."""
+    import torch
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--no-cpu", "--draws", "1000"]
+    m, a = _bench_module(args)
+    cmd = m.launcher_cmd(args, 2, 4711)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "4711"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == args                                   # everything after the script is bench.py's own line
+    seen = {}
+
+    def fake_call(c, env=None):
+        seen["cmd"], seen["env"] = c, env
+        seen["gpu_initialised"] = torch.cuda.is_initialized()
+        return 7
+
+    monkeypatch.setattr(m.subprocess, "call", fake_call)
+    monkeypatch.setattr(m.sys, "argv", ["bench.py"] + args)
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k_, raising=False)
+    try:
+        m.main()
+        raise AssertionError("main() returned instead of exiting with the children's code")
+    except SystemExit as e:
+        assert e.code == 7                                       # a failing child fails the parent
+    assert seen["gpu_initialised"] is False
+    assert seen["cmd"][seen["cmd"].index(os.path.join(ROOT, "bench.py")) + 1:] == args
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in seen["env"]
+    # RCCL needs one GPU per rank: without them the launcher refuses (rc 2) instead of starting ranks that cannot run
+    monkeypatch.setattr(m.sys, "argv", ["bench.py", "--gpus", "64"])
+    try:
+        m.main()
+        raise AssertionError
+    except SystemExit as e:
+        assert e.code == 2
+
+
+def test_bench_defaults_are_one_gpu_and_short():
+    m, a = _bench_module([])
     assert a.gpus == 1 and a.steps <= 50 and a.warmup <= 10
     assert a.draws == 100_000_000 and a.gibbs_n == 10_000_000 and a.gibbs_p == 64      # BASELINE configs C2, C4
     assert a.backend == "nccl"
+    assert not a.no_c5 and a.c5_rows == 12_500_000 and not a.no_mixed     # C3 and the C5 shard are in the default line

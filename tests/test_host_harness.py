@@ -144,3 +144,48 @@ def test_philox_rounds_in_stages(harness):
     for _ in range(2000):
         c = [int(v) for v in rng.integers(0, 2 ** 32, 6)]
         assert harness.sm_philox_staged_equal(*c)
+
+
+def _cap_build(cap):
+    """The same host object with a tiny per-draw block cap (-DBL_PG1_BLK_CAP): scaffolding for the two tests below."""
+    lib = os.path.join(HERE, "host_harness", f"libpg1_sm_host_cap{cap}.so")
+    hdr = os.path.join(HERE, "..", "bayeslogit_amd", "csrc", "bl_pg1_sm.hpp")
+    if not os.path.exists(lib) or max(os.path.getmtime(hdr), os.path.getmtime(SRC)) > os.path.getmtime(lib):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-DBL_PG1_BLK_CAP={cap}u", "-o", lib, SRC, "-lm"])
+    H = C.CDLL(lib)
+    H.sm_rpg_devroye.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_long, C.c_ulonglong,
+                                 C.c_uint, C.c_ulonglong, C.POINTER(C.c_int)]
+    return H
+
+
+def test_block_cap_is_per_draw_not_per_observation(harness, oracle):
+    """PolyaGamma::draw(int n, ...) sums n draws (PolyaGamma.cpp:126-140); the block cap that stands in for the
+    reference's uncapped loops counts from the start of EACH draw, so a large n is not truncated: with a cap of 48
+    blocks per draw an observation with n = 200 000 spends ~2.6e5 blocks, raises no flag and gives the sum of the
+    uncapped sampler (the oracle's) on the same stream."""
+    import oracle_lib as O
+    H = _cap_build(48)
+    z = np.array([0.0, 1.3, 3.9, 7.0])
+    n = np.array([200000, 150001, 70000, 30000], dtype=np.int32)
+    x = np.zeros(4)
+    st = C.c_int(0)
+    H.sm_rpg_devroye(O.dp(x), O.ip(n), O.dp(z), 4, 99, 0, 12345, C.byref(st))
+    assert st.value == 0
+    xo = oracle.rpg_devroye(4, n, z, 99, 0, 12345)
+    assert np.allclose(x, xo, rtol=1e-11, atol=0), (x, xo)
+
+
+def test_block_cap_fires_per_draw_and_is_flagged():
+    """With a cap of 2 blocks per draw some of 5000 draws need a third attempt (P ~ 2-7 %): the cap is hit, flagged
+    (BL_ST_ITER_CAP = 1) and the partial sum returned -- below the full sum of the same stream."""
+    import oracle_lib as O
+    H2, H48 = _cap_build(2), _cap_build(48)
+    z = np.array([2.0])
+    n = np.array([5000], dtype=np.int32)
+    x2, x48 = np.zeros(1), np.zeros(1)
+    st = C.c_int(0)
+    H2.sm_rpg_devroye(O.dp(x2), O.ip(n), O.dp(z), 1, 5, 0, 0, C.byref(st))
+    assert st.value & 1
+    st = C.c_int(0)
+    H48.sm_rpg_devroye(O.dp(x48), O.ip(n), O.dp(z), 1, 5, 0, 0, C.byref(st))
+    assert st.value == 0 and 0.0 <= x2[0] < x48[0]

@@ -166,3 +166,22 @@ def test_vlk_equals_oracle(hh, oracle):
         ref = oracle.sp_vlk(float(x))
         for a, b in zip(out, ref):
             assert abs(a - b) <= 1e-13 * max(1.0, abs(b))
+
+
+def test_alt_block_cap_is_per_draw(hh, oracle):
+    """PolyaGammaAlt::draw sums floor((h-1)/4) abridged draws at shape 4 plus the remainder (PolyaGammaAlt.cpp:205-225).
+    The block cap counts from the start of each abridged draw: built with a cap of 64 blocks, a group of 2500 draws
+    (h = 10001.5: ~4000 blocks) is not cut short, raises no flag and equals the default build on the same stream."""
+    lib = os.path.join(HERE, "host_harness", "libhyb_sm_host_cap64.so")
+    hdrs = glob.glob(os.path.join(HERE, "..", "bayeslogit_amd", "csrc", "*.hpp"))
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in hdrs + [SRC]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DBL_ALT_BLK_CAP=64u",
+                               "-o", lib, SRC, "-lm"])
+    Hc = C.CDLL(lib)
+    h = np.array([10001.5, 4003.0, 13.0])
+    z = np.array([0.7, 0.0, 2.5])
+    xc, stc = _run_alt(Hc, oracle, h, z, 31)
+    xd, std = _run_alt(hh, oracle, h, z, 31)
+    assert stc == 0 and std == 0 and np.array_equal(xc, xd)
+    m1 = h * np.tanh(np.maximum(z, 1e-12) / 2) / (2 * np.maximum(z, 1e-12))
+    assert np.all(np.abs(xc[:2] / m1[:2] - 1) < 0.05)           # E PG(h, z); sd/mean ~ 1 % at h = 4000
