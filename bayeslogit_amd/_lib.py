@@ -53,6 +53,8 @@ SIGNATURES = {
     "bl_rpg_gamma_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),
     "bl_diag_mfma_f64_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
     "bl_diag_mfma_f64_small_dev": (C.c_int, [c_vp, c_i64, C.c_int, C.c_int, C.POINTER(C.c_double), c_vp]),
+    "bl_diag_count_blocks_dev": (C.c_int, [c_vp, c_vp, c_i64, c_u64, c_u32, c_u64, c_vp, c_vp]),
+    "bl_diag_rpg_hybrid_class_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i64, C.c_int, c_u64, c_u32, c_u64, c_vp]),
     "bl_diag_sp_vlk_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "bl_fill_unif_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),
     "bl_fill_norm_dev": (C.c_int, [c_vp, c_i64, c_d, c_d, c_u64, c_u32, c_u64, c_vp]),

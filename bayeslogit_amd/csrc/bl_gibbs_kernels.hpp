@@ -23,7 +23,7 @@ struct SweepPlan {
   int nb = 0;             // fused: P/16
   int ntile = 0;          // generic: number of 64x64 output tiles (upper triangle)
   size_t partial_doubles = 0;   // workspace size
-  int single_pass = -1;         // P = 64: -1 follow bl_set_sweep_mode, 0 two passes, 1 one pass (a handle turns it off when most
+  int single_pass = -1;         // P = 64, 256: -1 follow bl_set_sweep_mode, 0 two passes, 1 one pass (a handle turns it off when most
                                 // of its rows leave the single pass's fast path: bl_gibbs_sweep_local)
 };
 SweepPlan make_plan(int64_t N, int P, int num_cus);
@@ -50,6 +50,16 @@ unsigned long long* sweep_once64_deferred_counter(double* ws, int nblocks, int64
 void launch_sweep_once64(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
                          double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
                          unsigned long long* stats, hipStream_t s);
+
+// The same at P = 256 (kernels_sweep256.hip): one workgroup of eight waves per CU multiplies tile i while wave 0 draws tile i+1
+// and tile i+2 arrives; same contract as launch_sweep_once64 (omega to the last bits, PPpart in another fixed order).
+size_t sweep_once256_ws_doubles(int nblocks, int64_t N);
+unsigned long long* sweep_once256_deferred_counter(double* ws, int nblocks, int64_t N);
+void launch_sweep_once256(int nblocks, const double* tX, const double* n, const double* beta, double* w, int64_t N,
+                          double* ws, double* PP, uint64_t seed, uint32_t epoch, uint64_t idx0, int* status,
+                          unsigned long long* stats, hipStream_t s);
+// the handle's counter of deferred rows of whichever single-pass sweep the plan has (P = 64, 256), or nullptr
+unsigned long long* sweep_once_deferred_counter(const SweepPlan& plan, double* ws, int64_t N);
 
 // X' Omega X for P = 128 (nc = 8 chunks of 16 columns) or 256 (nc = 16) on v_mfma_f64_4x4x4_4b_f64 (kernels_xwx4.hip),
 // one workgroup of nc/2 waves per block; partial: xwx_q4_big_ws_doubles(nblocks, nc) doubles.

@@ -18,9 +18,14 @@ bool ensure_device();                       // false => BL_ERR_NO_DEVICE recorde
 int* status_word(hipStream_t s);            // device int, zeroed per sync
 int  collect_status(hipStream_t s);         // sync + read + reset flags
 
-// kernels_tasks.hip: the alternating-series (sp == false) or saddle-point work-queue kernel over (h, z); x zeroed by the caller
+// kernels_tasks.hip: the alternating-series (sp == false) or saddle-point work-queue kernel over (h, z).  hybrid: 0 =
+// rpg_alt / rpg_sp (every h != 0 is a member; the kernel writes every element of x itself: no zeroing launch in front);
+// kHybFirst = the first class pass of rpg_hybrid: it also counts the members of every class into cls_count[6] and writes
+// the zeros of the b <= 0 branch; kHybLater = a later class pass: returns at once when cls_count says its class is empty.
+enum : int { kHybNone = 0, kHybFirst = 1, kHybLater = 2 };
 int launch_rpg_tasks(bool sp, double* x, const double* h, const double* z, int64_t num, int* iter, uint64_t seed,
-                     uint32_t epoch, uint64_t idx0, int hybrid, hipStream_t s);
+                     uint32_t epoch, uint64_t idx0, int hybrid, unsigned long long* cls_count, hipStream_t s);
+unsigned long long* class_counts_slot();    // 8 device counters for one rpg_hybrid call (a ring of 64 slots)
 
 uint64_t global_seed();
 uint32_t next_epoch();                      // returns current, then increments

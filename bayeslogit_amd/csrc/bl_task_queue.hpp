@@ -18,7 +18,9 @@
 // The Philox stream belongs to the observation (counter = global index; an alternating-series
 // observation's second task reads from block 2^31 on), so which lane draws a task, and when, does not
 // change the result.  The two tasks of an alternating-series observation add their sums into x[] with
-// one fp64 atomic each; x[] was zeroed by an earlier launch, and 0 + a + b = 0 + b + a bit for bit.
+// one fp64 atomic each; the wave that scans the chunk stores the 0 they are added to (no zeroing launch over x), and
+// 0 + a + b = 0 + b + a bit for bit.  Every element of x is written by exactly one kernel: members by their class's
+// launch, h == 0 / refused shapes (rpg_alt, rpg_sp) and the b <= 0 branch (rpg_hybrid's first pass) by the scan.
 #pragma once
 #include "bl_alt_sm.hpp"
 #include "bl_pg_hybrid.hpp"
@@ -136,15 +138,22 @@ struct AltPolicy {
 };
 
 // hybrid != 0: the members are the observations whose shape takes this sampler in rpg_hybrid
-// (LogitWrapper.cpp:142-161); the other classes' launches write the rest of x.  hybrid == 0 (rpg_alt,
-// rpg_sp): every h != 0 is a member (LogitWrapper.cpp:95-98, :116-120); a shape below 1 is refused
-// (PolyaGammaAlt.cpp:207-210: message and 0), flagged, and left at the 0 of the zeroing launch.
+// (LogitWrapper.cpp:142-161); the other classes' launches write the rest of x.  hybrid == 1 (the first class pass; the
+// scan reads every shape anyway): the members of EVERY class are counted into cls_count[6] -- the later passes
+// (hybrid == 2) return at once when their class is empty -- and the b <= 0 branch's zeros (:159-161) are written.
+// hybrid == 0 (rpg_alt, rpg_sp): every h != 0 is a member (LogitWrapper.cpp:95-98, :116-120); h == 0 gives 0; a shape
+// below 1 is refused (PolyaGammaAlt.cpp:207-210: message and 0; the saddle-point sampler only warns there,
+// PolyaGammaSP.cpp:171, and goes on into a truncated gamma of shape < 1, which the reference's own prototype of that
+// variate defines as NA, Code/R/Ch.R:91: refused here as well) and flagged; the scan writes those zeros.
 template <class P>
 __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double* __restrict__ x, const double* __restrict__ h,
                                                           const double* __restrict__ z, int64_t num,
                                                           int* __restrict__ iter, uint64_t seed, uint32_t epoch,
-                                                          uint64_t idx0, int hybrid, int* __restrict__ status)
+                                                          uint64_t idx0, int hybrid,
+                                                          unsigned long long* __restrict__ cls_count,
+                                                          int* __restrict__ status)
 {
+  if (hybrid == 2 && cls_count[P::kCls] == 0) return;       // (uniform) nothing of this class in the vector
   constexpr int NW = kTqBlock / 64;
   constexpr int kList = kTqChunk * P::kMaxTasksPerObs;
   __shared__ unsigned short sList[NW][kList];               // (offset in chunk) << 1 | group
@@ -168,6 +177,8 @@ __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double
   typename P::Task T;
   int64_t row = -1;          // -1: idle
   bool two = false;
+  __shared__ unsigned sCls[NW][8];                          // hybrid == 1: members of every class this wave has scanned
+  if (lane < 8) sCls[wave][lane] = 0u;                      // (in LDS: six more live registers cost the saddle-point kernel a spill)
 
   const int64_t nchunks = (num + kTqChunk - 1) / kTqChunk;
   for (int64_t ch = (int64_t)blockIdx.x * NW + wave; ch < nchunks; ch += (int64_t)gridDim.x * NW) {
@@ -187,15 +198,26 @@ __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = (j0 + j) * 64 + lane;
-        bool mine;
+        bool mine, zero;
         if (hybrid) {
-          mine = k < cnt && pg_class(hk[j]) == P::kCls;
+          const int cls = k < cnt ? pg_class(hk[j]) : -1;
+          mine = cls == P::kCls;
+          zero = hybrid == 1 && cls == CLS_ZERO;
+          if (hybrid == 1) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              const unsigned nc = (unsigned)__popcll(__ballot(cls == c));
+              if (lane == c) sCls[wave][c] += nc;
+            }
+          }
         } else {
           mine = k < cnt && hk[j] != 0.0;
           if (mine && !(hk[j] >= 1.0)) { mine = false; st_flags |= ST_BAD_SHAPE; }
+          zero = k < cnt && !mine;
         }
         int nA = 0;
         const bool second = mine && P::groups(hk[j], nA) == 2;
+        if (zero || second) x[base + k] = 0.0;     // the value itself, or what the observation's two tasks add their sums to
         const uint64_t mB = __ballot(mine), mA = __ballot(second);
         if (mine) list[nT + __popcll(mB & lt_mask)] = (unsigned short)(k << 1);
         nT += __popcll(mB);
@@ -205,7 +227,8 @@ __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // (workgroup scope: the zeros above have reached L2, where this wave's atomics on them execute, before any is issued)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // ---- 64 tasks at a time: set-up, then the queue
     for (int i0 = 0; i0 < nT; i0 += 64) {
@@ -239,6 +262,9 @@ __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double
           }
           next += __popcll(im);
         }
+        // every staged task has been started and some lanes found none: no step for a partly filled wave -- the lanes inside
+        // a task stay in flight and the next 64 staged tasks fill the idle ones (bl_pg1_queue.hpp has the measurement)
+        if (next >= nb && __ballot(row >= 0) != ~0ull) break;
         if (row >= 0) {
           if (P::step(T, vt, epoch, k0, k1, st_flags)) {
             P::emit(T, x, iter, row, two);
@@ -260,6 +286,7 @@ __global__ __launch_bounds__(kTqBlock, P::kWavesPerSimd) void k_rpg_tasks(double
     }
   }
   if (st_flags) atomicOr(status, st_flags);
+  if (hybrid == 1 && lane < 6 && sCls[wave][lane]) atomicAdd(&cls_count[lane], (unsigned long long)sCls[wave][lane]);
 }
 
 }  // namespace bl

@@ -167,9 +167,9 @@ int bl_gibbs_chain_start(bl_gibbs* h)
   h->draw_sweeps_at_check = 0;
   h->plan.single_pass = -1;
   BL_HIP_TRY(hipMemsetAsync(h->dead, 0, sizeof(int), h->stream));
-  if (h->P == 64 && h->N > 0)
-    BL_HIP_TRY(hipMemsetAsync(blk::sweep_once64_deferred_counter(h->partial, h->plan.nblocks, h->N), 0,
-                              sizeof(unsigned long long), h->stream));
+  if ((h->P == 64 || h->P == 256) && h->N > 0)
+    BL_HIP_TRY(hipMemsetAsync(blk::sweep_once_deferred_counter(h->plan, h->partial, h->N), 0, sizeof(unsigned long long),
+                              h->stream));
   return BL_OK;
 }
 
@@ -179,14 +179,14 @@ int bl_gibbs_sweep_local(bl_gibbs* h, uint32_t sweep, double* w_out)
   blk::launch_sweep(h->plan, h->tX, h->n, h->beta, nullptr, w_out, h->wscr, h->N, h->partial, h->PP, h->seed, sweep,
                     h->idx0, blk::W_DRAW, blh::status_word(h->stream), h->stream);
   BL_HIP_TRY(hipGetLastError());
-  // The single-pass sweep (P = 64) hands rows outside its fast path -- |psi|/2 >= 1/t, n != 1, four attempts all retries --
+  // The single-pass sweep (P = 64, 256) hands rows outside its fast path -- |psi|/2 >= 1/t, n != 1, four attempts all retries --
   // to a second kernel; when a fifth of the rows go that way the two passes are faster (rare-event data: most |psi| > 3.1).
   // Looked at after this handle's 8th and 64th sweep (one stream synchronisation each): a decision that depends on the
   // data and the chain only, so a run is reproducible; omega does not depend on it, X'Omega X in its last bits.
   h->draw_sweeps += 1;
-  if (h->P == 64 && h->N > 0 && h->plan.single_pass < 0 && blh::sweep_single_pass() &&
+  if ((h->P == 64 || h->P == 256) && h->N > 0 && h->plan.single_pass < 0 && blh::sweep_single_pass() &&
       (h->draw_sweeps == 8 || h->draw_sweeps == 64)) {
-    unsigned long long* ctr = blk::sweep_once64_deferred_counter(h->partial, h->plan.nblocks, h->N);
+    unsigned long long* ctr = blk::sweep_once_deferred_counter(h->plan, h->partial, h->N);
     unsigned long long cnt = 0;
     BL_HIP_TRY(hipMemcpyAsync(&cnt, ctr, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
     BL_HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(cnt), h->stream));

@@ -32,6 +32,8 @@ std::atomic<int> g_beta_sweeps{initial_beta_sweeps()};
 std::atomic<int> g_sweep_mode{initial_sweep_mode()};
 unsigned long long* g_sweep_stats_dev = nullptr;     // [0] rows that left the single-pass sweep's fast path
 int* g_status_dev = nullptr;
+unsigned long long* g_class_counts_dev = nullptr;    // 64 slots of 8: per-class member counts of one rpg_hybrid call
+std::atomic<unsigned> g_class_slot{0};
 bool g_dev_ok = false, g_dev_tried = false;
 }  // namespace
 
@@ -60,6 +62,7 @@ bool ensure_device()
   if (e == hipSuccess) e = hipMemset(g_status_dev, 0, sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&g_sweep_stats_dev, 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(g_sweep_stats_dev, 0, 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&g_class_counts_dev, 64 * 8 * sizeof(unsigned long long));
   if (e != hipSuccess) {
     g_err = std::string("hipMalloc(status): ") + hipGetErrorString(e);
     fprintf(stderr, "bayeslogit_hip: %s\n", g_err.c_str());
@@ -103,6 +106,7 @@ int global_constrain() { return g_constrain.load(); }
 int sweep_single_pass() { return g_sweep_mode.load(); }
 int beta_sweeps_kind() { return g_beta_sweeps.load(); }
 unsigned long long* sweep_stats() { return g_sweep_stats_dev; }
+unsigned long long* class_counts_slot() { return g_class_counts_dev + 8 * (g_class_slot.fetch_add(1) & 63u); }
 
 }  // namespace blh
 

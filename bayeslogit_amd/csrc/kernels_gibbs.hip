@@ -888,6 +888,13 @@ static void plan_draw_pass(SweepPlan& p, int64_t N, int num_cus)
   p.nblocks_draw = (int)nd;
 }
 
+unsigned long long* sweep_once_deferred_counter(const SweepPlan& plan, double* ws, int64_t N)
+{
+  if (plan.P == 64) return sweep_once64_deferred_counter(ws, plan.nblocks, N);
+  if (plan.P == 256) return sweep_once256_deferred_counter(ws, plan.nblocks, N);
+  return nullptr;
+}
+
 SweepPlan make_plan(int64_t N, int P, int num_cus)
 {
   SweepPlan p;
@@ -902,6 +909,8 @@ SweepPlan make_plan(int64_t N, int P, int num_cus)
     plan_draw_pass(p, N, num_cus);
     p.partial_doubles = (size_t)p.nblocks * (p.nb * (p.nb + 1) / 2) * 256;
     if (xwx_q4_big_ws_doubles(p.nblocks, p.nb) > p.partial_doubles) p.partial_doubles = xwx_q4_big_ws_doubles(p.nblocks, p.nb);
+    if (P == 256 && sweep_once256_ws_doubles(p.nblocks, N) > p.partial_doubles)       // the single-pass sweep's workspace
+      p.partial_doubles = sweep_once256_ws_doubles(p.nblocks, N);
   } else if (P >= 1 && P <= 64) {
     p.fused = 1;
     p.nb = (P + 15) / 16;                        // columns padded (as zeros, in registers) to 16 nb
@@ -935,6 +944,13 @@ void launch_sweep(const SweepPlan& plan, const double* tX, const double* n, cons
 {
   const int P = plan.P;
   double* w = w_store ? w_store : w_scratch;
+  if (plan.fused == 2 && plan.P == 256 && mode == W_DRAW && !off && parts == 3 && !xoc && N > 0 &&
+      (plan.single_pass < 0 ? blh::sweep_single_pass() : plan.single_pass)) {
+    // X read once (kernels_sweep256.hip); omega is stored only if the caller wants it
+    launch_sweep_once256(plan.nblocks, tX, n, beta, w_store, N, partial, PPpart, seed, epoch, idx0, status,
+                         blh::sweep_stats(), s);
+    return;
+  }
   if (plan.fused == 2) {
     if (plan.nb == 8)
       launch_nb_big<8, 4>(plan, tX, n, beta, off, w, N, partial, PPpart, seed, epoch, idx0, mode, status, s, parts);

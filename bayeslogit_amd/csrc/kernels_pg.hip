@@ -149,8 +149,10 @@ __global__ __launch_bounds__(kBlock, 3) void k_rpg_hybrid_class(double* __restri
                                                              const double* __restrict__ h,
                                                              const double* __restrict__ z, int64_t num,
                                                              uint64_t seed, uint32_t epoch, uint64_t idx0,
+                                                             const unsigned long long* __restrict__ cls_count,
                                                              int* __restrict__ status)
 {
+  if (cls_count && cls_count[CLS] == 0) return;          // (uniform) the first class pass found no member of this class
   static_assert(CLS == CLS_DEVROYE || CLS == CLS_NORMAL || CLS == CLS_GAMMA, "the other classes run as tasks");
   constexpr int NKEY = CLS == CLS_DEVROYE ? 2 : 1;      // Devroye: one draw (b = 1) or two (b = 2)
   __shared__ unsigned short sIdx[kBlock / 64][kChunkH];
@@ -373,14 +375,40 @@ int bl_rpg_hybrid_dev(double* x, const double* h, const double* z, int64_t num, 
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(blh::grid_for(num, kBlock, kMaxBlocks)), b(kBlock);
   int* st = blh::status_word(s);
-  // Every class pass is launched; a pass whose class is absent costs one read of h.  x is zeroed first: that is
-  // the b <= 0 branch (LogitWrapper.cpp:159-161), and the alternating-series tasks add their sums into it.
-  BL_HIP_TRY(hipMemsetAsync(x, 0, sizeof(double) * (size_t)num, s));
-  if (int rc = blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, 1, s)) return rc;    // saddle point
-  if (int rc = blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, 1, s)) return rc;   // alternating series
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
-  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, st);
+  // Classified once: the first class pass (saddle point; its scan reads every shape) counts the members of every class and
+  // writes the b <= 0 branch's zeros (LogitWrapper.cpp:159-161); a later pass whose class is empty returns at once.  No
+  // zeroing launch over x: every element is written by exactly one pass.
+  unsigned long long* cc = blh::class_counts_slot();
+  BL_HIP_TRY(hipMemsetAsync(cc, 0, 8 * sizeof(unsigned long long), s));
+  if (int rc = blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybFirst, cc, s)) return rc;    // saddle point
+  if (int rc = blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybLater, cc, s)) return rc;   // alternating series
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
+  hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
+  BL_HIP_TRY(hipGetLastError());
+  return BL_OK;
+}
+
+// diagnostic (bench.py's per-branch rates of C3): ONE class pass of rpg_hybrid alone -- cls = 4 saddle point, 3 alternating
+// series, 2 Devroye, 5 normal approximation, 1 sum of gammas -- writing only that class's elements of x.
+int bl_diag_rpg_hybrid_class_dev(double* x, const double* h, const double* z, int64_t num, int cls, uint64_t seed,
+                                 uint32_t epoch, uint64_t idx0, void* stream)
+{
+  if (int rc = check_args(x, z, num)) return rc;
+  if (num == 0) return BL_OK;
+  if (!h) { blh::set_error("h is null"); return BL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(blh::grid_for(num, kBlock, kMaxBlocks)), b(kBlock);
+  int* st = blh::status_word(s);
+  const unsigned long long* none = nullptr;
+  switch (cls) {
+    case bl::CLS_SP: return blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybLater + 1, nullptr, s);
+    case bl::CLS_ALT: return blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybLater + 1, nullptr, s);
+    case bl::CLS_DEVROYE: hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, none, st); break;
+    case bl::CLS_NORMAL: hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, none, st); break;
+    case bl::CLS_GAMMA: hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, none, st); break;
+    default: blh::set_error("bl_diag_rpg_hybrid_class_dev: cls must be 1..5"); return BL_ERR_ARG;
+  }
   BL_HIP_TRY(hipGetLastError());
   return BL_OK;
 }

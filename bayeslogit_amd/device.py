@@ -87,6 +87,29 @@ def mfma_f64_sustained_tflops(waves_per_simd=2, iters=4000, small=False):
     return best
 
 
+CLASS_NAMES = ("zero", "sum_of_gammas", "devroye", "alternating_series", "saddle_point", "normal_approximation",
+               "devroye_wide_z")          # the last: the part of "devroye" with |z|/2 >= 1/t (the other left-piece sampler)
+
+
+def count_blocks(h, z, seed=0, epoch=0, idx0=0):
+    """Per sampler class {observations, draws, Philox blocks (= proposal attempts)} of the draws rpg_hybrid(h, z) -- or, h None,
+    rpg_devroye(z, n = 1) -- makes on these streams (bl_diag_count_blocks_dev: an exact replay, one observation per lane)."""
+    out = torch.zeros(21, dtype=torch.int64, device=z.device)
+    _lib.check(_lib.lib().bl_diag_count_blocks_dev(_ptr(h), _ptr(_f64(z, "z")), z.numel(), seed, epoch, idx0, _ptr(out), _stream()),
+               "bl_diag_count_blocks_dev")
+    o = out.cpu().numpy().reshape(7, 3)
+    return {CLASS_NAMES[c]: {"observations": int(o[c, 0]), "draws": int(o[c, 1]), "blocks": int(o[c, 2])}
+            for c in range(7) if o[c, 0] > 0}
+
+
+def rpg_hybrid_class(h, z, cls, seed=0, epoch=0, idx0=0, out=None):
+    """ONE class pass of rpg_hybrid alone (bl_diag_rpg_hybrid_class_dev): only that class's elements of `out` are written."""
+    x = torch.empty_like(z) if out is None else _f64(out, "out")
+    _lib.check(_lib.lib().bl_diag_rpg_hybrid_class_dev(_ptr(x), _ptr(_f64(h, "h")), _ptr(_f64(z, "z")), z.numel(), int(cls), seed,
+                                                       epoch, idx0, _stream()), "bl_diag_rpg_hybrid_class_dev")
+    return x
+
+
 def fill_unif(out, lo, hi, seed, epoch=0, idx0=0):
     _lib.check(_lib.lib().bl_fill_unif_dev(_ptr(_f64(out, "out")), out.numel(), lo, hi, seed, epoch, idx0, _stream()),
                "bl_fill_unif_dev")

@@ -158,6 +158,58 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def flops_table():
+    """profiles/flops_table.json (scripts/count_flops.py: VALU instructions and fp64 flops per call, counted in the gfx950 ISA)."""
+    try:
+        with open(os.path.join(HERE, "profiles", "flops_table.json")) as f:
+            return json.load(f)["per_call"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def devroye_work(D, z, seed, epoch, idx0, draws_per_s):
+    """SURVEY 8d for the PG(1,z) kernel: mean attempts (Philox blocks) per draw on THIS input -- an exact replay of the
+    streams the timed kernel drew from -- and, through the flops-per-call table, the fp64 VALU op rate the measured
+    draws/s amount to, against the 78.6 TFLOP/s vector peak."""
+    n = min(z.numel(), 20_000_000)
+    c = D.count_blocks(None, z[:n], seed=seed, epoch=epoch, idx0=idx0)
+    dv = c["devroye"]
+    wide = c.get("devroye_wide_z", {"observations": 0, "draws": 0, "blocks": 0})
+    nar = {k: dv[k] - wide[k] for k in dv}
+    out = {"replayed_draws": dv["draws"], "attempts_per_draw": dv["blocks"] / dv["draws"],
+           "attempts_per_draw_small_z": nar["blocks"] / max(nar["draws"], 1),
+           "attempts_per_draw_wide_z": (wide["blocks"] / wide["draws"]) if wide["draws"] else None,
+           "share_wide_z": wide["draws"] / dv["draws"],
+           "note": "attempt = one Philox4x32-10 block = one pass of the attempt body (bl_pg1_sm.hpp); small_z / wide_z: "
+                   "|z|/2 < 1/t resp. >= 1/t, the two left-piece samplers of PolyaGamma.cpp:87-113; the reference's own "
+                   "count is 1.0007 proposals x 1.0016 series terms per draw (Notes/notes.tex:1000-1027) with the inner "
+                   "rejection loops of rtigauss counted inside a proposal -- here each inner retry is an attempt"}
+    ft = flops_table()
+    if ft:
+        f1 = ft["attempt_class1"]["fp64_flops"] + ft["philox"]["fp64_flops"]
+        f2 = ft["attempt_class2"]["fp64_flops"] + ft["philox"]["fp64_flops"]
+        s1 = ft["mass_small"]["fp64_flops"] + 2 * ft["div"]["fp64_flops"] + 3      # mass, the two reciprocals, fz
+        s2 = ft["mass_general"]["fp64_flops"] + 2 * ft["div"]["fp64_flops"] + 3
+        v1 = ft["attempt_class1"]["valu_instructions"] + ft["philox"]["valu_instructions"]
+        v2 = ft["attempt_class2"]["valu_instructions"] + ft["philox"]["valu_instructions"]
+        nd = dv["draws"]
+        flops = (nar["blocks"] * f1 + wide["blocks"] * f2 + nar["draws"] * s1 + wide["draws"] * s2) / nd
+        valu = (nar["blocks"] * v1 + wide["blocks"] * v2 + nar["draws"] * (ft["mass_small"]["valu_instructions"] + 16)
+                + wide["draws"] * (ft["mass_general"]["valu_instructions"] + 16)) / nd
+        tf = flops * draws_per_s / 1e12
+        out["fp64_valu"] = {"flops_per_draw": flops, "useful_valu_lane_instructions_per_draw": valu,
+                            "achieved_tflops": tf, "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                            "flops_per_call": {k: ft[k]["fp64_flops"] for k in ("log", "exp", "div", "sqrt", "philox", "mass_small",
+                                                                               "mass_general", "attempt_class1", "attempt_class2")},
+                            "valu_instructions_per_call": {k: ft[k]["valu_instructions"] for k in ("log", "exp", "div", "philox",
+                                                                                                   "attempt_class1", "attempt_class2")},
+                            "note": "flops per call counted in the gfx950 ISA (scripts/count_flops.py -> profiles/flops_table.json: "
+                                    "v_fma_f64 = 2, v_mul/v_add_f64 = 1, conversions, seeds, compares, selects and the Philox integer "
+                                    "multiplies 0) x the replayed attempt counts; the draw kernels are bound by VALU ISSUE SLOTS "
+                                    "(valu.busy_frac_of_cu_cycles), of which fp64 FMAs are about half"}
+    return out
+
+
 def time_allreduce(numel, world, dev, reps=50):
     """The sweep's one exchange on its own: all-reduce(sum) of `numel` doubles (P*P), microseconds per call, max over
     ranks (barrier + synchronize on both sides; 5 untimed calls first)."""
@@ -402,6 +454,7 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         t2, _ = pmc_traffic("k_sweep_deferred64")
         roof["traffic"] = (t1 + (t2 or 0.0)) if (t1 and N == 10_000_000 and world == 1) else None
         roof["traffic_source"] = src
+        roof["traffic_measured_in_this_run"] = False
     elif P < 64:
         nbk = (P + 15) // 16
         kernels = f"k_psi_omega_nb<{nbk},0> + k_xwx_mfma<{nbk}> + k_reduce_fused<{nbk}>"
@@ -421,9 +474,13 @@ def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, 
         tf = flops / (sk * 1e-3) / 1e12
         xk = ("k_xwx_q4_blk16 + k_reduce_q4_blk16" if P == 256 else "k_xwx_q4_big<8> + k_reduce_q4_big<8>" if P == 128
               else f"k_xwx_mfma_big<{nbk},8> + k_reduce_big<{nbk}>")
+        t1, src = pmc_traffic(f"k_psi_omega_nb<{nbk}, 0, true>")
+        t2, _ = pmc_traffic("k_xwx_q4_blk16" if P == 256 else "k_xwx_q4_big<8>")
         roof = {"kernel": f"k_psi_omega_nb<{nbk},0> + " + xk, "bound": "mfma",
                 "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None, "algorithmic_flops_per_launch": flops,
+                "traffic": (t1 + t2) if (t1 and t2 and nl == 12_500_000 and P == 256) else None, "traffic_source": src,
+                "traffic_measured_in_this_run": False, "algorithmic_bytes_per_launch": 8 * nl * P,
+                "algorithmic_flops_per_launch": flops,
                 "note": "whole sweep time (both passes) against the fp64 MFMA peak; X' Omega X alone is "
                         "k_xwx_q4_blk16 (P = 256) / k_xwx_q4_big<8> (P = 128) in profiles/"}
     roof["kernel_ms"] = sk
@@ -500,6 +557,7 @@ def main():
     D.sync_status()
     draws_per_s = n * world * a.steps / wall
     mean_x = x.mean().item()
+    work2 = devroye_work(D, z, 20240002, 0, idx0, n / (kern_ms * 1e-3)) if rank == 0 else None
     ach_gbs = BYTES_PER_DRAW * n / (kern_ms * 1e-3) / 1e9
     t_a, c2_traffic_src = pmc_traffic("k_rpg_devroye")
     # the committed counters are of the default workload
@@ -529,15 +587,18 @@ def main():
             "bound": "hbm",
             "limiter": "valu (scalar fp64 transcendental work; see the valu object)",
             "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-            "traffic": c2_traffic, "traffic_source": c2_traffic_src,
-            # the binding resource (same PMC summary; per launch of the default 1e8-draw workload)
+            "traffic": c2_traffic, "traffic_source": c2_traffic_src, "traffic_measured_in_this_run": False,
+            "work": work2,
+            # the binding resource (same PMC summary, a committed profile of this command; per launch of the default 1e8-draw workload)
             "valu": {k: {"wave_insts_per_launch": pmc_entry(k).get("valu_insts_per_launch"),
                          "busy_frac_of_cu_cycles": pmc_entry(k).get("valu_busy_frac"),
                          "issue_slot_frac_lower_bound": pmc_entry(k).get("valu_issue_frac_min"),
                          "wait_frac_of_wave_cycles": pmc_entry(k).get("wait_any_frac"),
                          "issue_stall_frac_of_wave_cycles": pmc_entry(k).get("wait_inst_frac"),
                          "salu_insts_per_valu_inst": pmc_entry(k).get("salu_per_valu"),
-                         "lds_bank_conflict_frac_of_lds_cycles": pmc_entry(k).get("lds_conflict_frac")}
+                         "lds_bank_conflict_frac_of_lds_cycles": pmc_entry(k).get("lds_conflict_frac"),
+                         "active_lane_frac": pmc_entry(k).get("active_lane_frac"),
+                         "source": "committed profile " + str(c2_traffic_src) + " (rocprofv3 --pmc passes of this command)"}
                      for k in ("k_rpg_devroye",)},
             "kernel_ms": kern_ms,
             "algorithmic_bytes_per_launch": BYTES_PER_DRAW * n,
@@ -555,25 +616,67 @@ def main():
         w3, k3 = timed_steps(lambda: D.rpg_hybrid(hh, zz, seed=20240002, idx0=idx0, out=xx), a.mixed_steps, 1, world, dev)
         D.sync_status()
         gb3 = BYTES_PER_DRAW_VEC * n / (k3 * 1e-3) / 1e9
-        tq = {k: pmc_entry(k) for k in ("bl::k_rpg_tasks<bl::SpPolicy>", "bl::k_rpg_tasks<bl::AltPolicy>")}
+        # every launch of one rpg_hybrid call, in launch order (profiles/ kernel names)
+        c3_kernels = ("bl::k_rpg_tasks<bl::SpPolicy>", "bl::k_rpg_tasks<bl::AltPolicy>", "k_rpg_hybrid_class<2>",
+                      "k_rpg_hybrid_class<5>", "k_rpg_hybrid_class<1>")
+        tq = {k: pmc_entry(k) for k in c3_kernels}
+        per_kernel_traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tq.items()}
+        have_all = n == 100_000_000 and per_kernel_traffic[c3_kernels[0]] and per_kernel_traffic[c3_kernels[1]]
+        # per-branch rates: every class pass alone, event-timed, next to the replayed attempt counts
+        branches = None
+        if rank == 0:
+            cnt = D.count_blocks(hh[:min(n, 20_000_000)], zz[:min(n, 20_000_000)], seed=20240002, idx0=idx0)
+            scale = n / min(n, 20_000_000)
+            branches = {}
+            for cls, name in ((4, "saddle_point"), (3, "alternating_series"), (2, "devroye"), (5, "normal_approximation"),
+                              (1, "sum_of_gammas")):
+                ms = []
+                for rep in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    D.rpg_hybrid_class(hh, zz, cls, seed=20240002, idx0=idx0, out=xx)
+                    e1.record()
+                    e1.synchronize()
+                    if rep:
+                        ms.append(e0.elapsed_time(e1))
+                c = cnt.get(name, {"observations": 0, "draws": 0, "blocks": 0})
+                obs = c["observations"] * scale
+                branches[name] = {"observations": int(obs), "share": obs / n, "kernel_ms_alone": float(np.mean(ms)),
+                                  "M_observations_per_s": (obs / (np.mean(ms) * 1e-3) / 1e6) if obs else None,
+                                  "pg_draws_per_observation": (c["draws"] / c["observations"]) if c["observations"] else None,
+                                  "attempts_per_draw": (c["blocks"] / c["draws"]) if c["draws"] and c["blocks"] else None}
+            D.sync_status()
+            branches["note"] = ("each class pass of rpg_hybrid launched alone over the whole vector (bl_diag_rpg_hybrid_class_dev: "
+                                "it scans every shape and draws its own class), HIP events, mean of 2 after a warm-up; an empty "
+                                "class's pass alone still scans (inside rpg_hybrid it returns at once: the first pass counts "
+                                "the classes); attempts = Philox blocks from an exact replay of the streams of the first "
+                                f"{min(n, 20_000_000)} observations (alternating series: per abridged draw of "
+                                "PolyaGammaAlt::draw's sum; saddle point: per proposal attempt, the reference's `iter` counts "
+                                "iterations of its outer loop only)")
         out["mixed"] = {
             "workload": ("C3: " if n == 100_000_000 else "C3 at reduced size: ") +
                         f"N={n:.3g} draws per GPU, b in {{1..50}} (4 % Devroye, 22 % alternating series, 74 % saddle point), "
                         "z~N(0,sd^2=2), through rpg_hybrid",
             "value": n * world * a.mixed_steps / w3 / 1e6, "unit": "M draws/s", "M_draws_per_s": n * world * a.mixed_steps / w3 / 1e6,
             "steps": a.mixed_steps, "ms_per_step": w3 / a.mixed_steps * 1e3, "sample_mean": xx.mean().item(),
+            "branches": branches,
             "roofline": {
-                "kernel": "k_rpg_tasks<SpPolicy> + k_rpg_tasks<AltPolicy> + k_rpg_hybrid_class<2,5,1> (one launch per sampler "
-                          "class) behind a zeroing memset",
+                "kernel": "k_rpg_tasks<SpPolicy> (first pass: also counts the classes and writes the b <= 0 zeros) + "
+                          "k_rpg_tasks<AltPolicy> + k_rpg_hybrid_class<2,5,1> (one launch per sampler class; a class without "
+                          "members returns at once; no zeroing launch)",
                 "bound": "hbm", "limiter": "valu (scalar fp64 transcendental work; see the valu object)",
                 "achieved": gb3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb3 / HBM_PEAK_GBS,
-                "traffic": (sum(v.get("hbm_bytes_per_launch", 0.0) for v in tq.values()) or None) if n == 100_000_000 else None,
-                "traffic_source": c2_traffic_src, "kernel_ms": k3, "algorithmic_bytes_per_launch": BYTES_PER_DRAW_VEC * n,
+                # the sum over ALL launches of one call (round 2 summed the two task kernels only)
+                "traffic": sum(v or 0.0 for v in per_kernel_traffic.values()) if have_all else None,
+                "traffic_per_kernel": per_kernel_traffic if have_all else None,
+                "traffic_source": c2_traffic_src, "traffic_measured_in_this_run": False,
+                "kernel_ms": k3, "algorithmic_bytes_per_launch": BYTES_PER_DRAW_VEC * n,
                 "valu": {k: {"wave_insts_per_launch": v.get("valu_insts_per_launch"),
                              "busy_frac_of_cu_cycles": v.get("valu_busy_frac"),
                              "issue_slot_frac_lower_bound": v.get("valu_issue_frac_min"),
                              "wait_frac_of_wave_cycles": v.get("wait_any_frac"),
-                             "issue_stall_frac_of_wave_cycles": v.get("wait_inst_frac")} for k, v in tq.items()},
+                             "issue_stall_frac_of_wave_cycles": v.get("wait_inst_frac"),
+                             "active_lane_frac": v.get("active_lane_frac")} for k, v in tq.items() if v},
             },
         }
         del zz, hh, xx
@@ -597,6 +700,12 @@ def main():
         ncores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
         sample = 3_000_000 * max(1, min(ncores, 16))
         one, allc = cpu_baseline(sample, ncores)
+        out["vs_baseline"] = out["value"] / (allc / 1e6)
+        out["vs_baseline_note"] = (f"value / cpu_baseline.value: the oracle (this repository's C restatement of the reference's "
+                                   f"loops; parity to the reference's own binary unpinned, DESIGN.md 1) on {ncores} host cores of this "
+                                   "box, same run.  BASELINE.md's only published figure for this metric is 2.3-2.5 M PG(1,0) draws/s "
+                                   "on one core of a 2012 desktop (Code/C/test_pgpar.cpp:74-76): see vs_published_pg10_serial")
+        out["vs_published_pg10_serial"] = out["value"] / 2.4
         out["cpu_baseline"] = {
             "value": allc / 1e6, "unit": "M draws/s", "cores": ncores, "kind": "port",
             "sample": f"{sample} PG(1,z) draws, z~Unif(0,4), oracle (C restatement of PolyaGamma.cpp:151-202), "
@@ -614,7 +723,11 @@ def main():
             tm["extrapolation"] = f"linear in rows: x {tm['rows']}/{a.gibbs_n}"
             out["cpu_baseline"]["gibbs"] = tm
             out["gibbs"]["vs_cpu_1_core_extrapolated"] = out["gibbs"]["value"] / tm["sweeps_per_s_extrapolated_to_gibbs_n"]
+            out["gibbs"]["vs_cpu_note"] = ("CPU side = the oracle (repo restatement of Logit.hpp:402-481; parity to the reference "
+                                           "binary unpinned), one core, timed at cpu_baseline.gibbs.rows rows and extrapolated "
+                                           "linearly in the rows")
             if "posterior" in cg:
+                cg["posterior"]["cpu_side"] = "oracle (repo restatement), parity to the reference binary unpinned"
                 out["gibbs"]["posterior_vs_cpu"] = cg["posterior"]
 
     if rank == 0:

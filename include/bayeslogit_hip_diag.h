@@ -38,6 +38,18 @@ void bl_diag_beta_sweeps(int row_split);
  * from the fitted table of bl_vtab.hpp (x > 0; device pointers).  v is what the reference's v_eval returns
  * (Code/C/InvertY.cpp:57-99: table bracket + Newton solve to |dv| <= 1e-9); tests/test_inverty_ref.py compares the two. */
 int bl_diag_sp_vlk_dev(double *out3, const double *x, int64_t num, void *stream);
+/* ONE class pass of rpg_hybrid alone (bench.py times them one by one for the per-branch rates of config C3): cls = 4 saddle
+ * point, 3 alternating series, 2 Devroye, 5 normal approximation, 1 sum of gammas; only that class's elements of x are written. */
+int bl_diag_rpg_hybrid_class_dev(double *x, const double *h, const double *z, int64_t num, int cls,
+                                 uint64_t seed, uint32_t epoch, uint64_t idx0, void *stream);
+/* How much work the draws of a vector are (mean retry count per draw): out21[3 c + 0..2] (device, unsigned 64-bit) =
+ * {observations, PG draws, Philox blocks = proposal attempts} of sampler class c (0 zero, 1 sum of gammas, 2 Devroye, 3
+ * alternating series, 4 saddle point, 5 normal approximation; rpg_hybrid's dispatch, LogitWrapper.cpp:142-161; row 6 = the part of
+ * row 2 with |z|/2 >= 1/t, which takes the other left-piece sampler, PolyaGamma.cpp:103).  h == NULL:
+ * rpg_devroye with n = 1.  A replay of every observation's stream by the production attempt bodies, one observation per lane
+ * (slow, exact: a draw is a function of its stream alone, so these are the counts of the production kernels). */
+int bl_diag_count_blocks_dev(const double *h, const double *z, int64_t num, uint64_t seed, uint32_t epoch, uint64_t idx0,
+                             unsigned long long *out21, void *stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,10 @@ and, from the "mfma" pass:
                            adds 64 cycles per v_mfma_f64_16x16x4_f64 and 16 per v_mfma_f64_4x4x4_4b_f64 (nominal pass counts:
                            the measured issue intervals are 101.7 and 12.4 cycles, scripts/experiments/mfma_f64_shapes.hip)
   lds_insts_per_launch   = SQ_INSTS_LDS
+and, from the "lanes" pass (r03):
+  active_lane_frac       = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of the 64 lanes that are enabled, averaged
+                           over the cycles a vector instruction executes (rocprofiler's VALUUtilization / 100): 1 - this is what
+                           divergence (exec masks of the queue's refill path, class branches, rare paths) costs
 """
 import collections
 import csv
@@ -37,7 +41,7 @@ tag = sys.argv[1]
 KEEP = ("k_rpg", "k_psi", "k_xwx", "k_beta", "k_reduce", "k_sweep")
 SIMDS = 256 * 4
 summary = collections.defaultdict(dict)
-for kind in ("fetch", "write", "valu", "stall", "mfma"):
+for kind in ("fetch", "write", "valu", "stall", "mfma", "lanes"):
     files = glob.glob(f"gpurun_out/pmc_{kind}_{tag}/**/*counter_collection.csv", recursive=True)
     if not files:
         print(kind, "no counter file")
@@ -86,6 +90,8 @@ for name, m in summary.items():
             e["salu_per_valu"] = m.get("SQ_INSTS_SALU", 0.0) / m["SQ_INSTS_VALU"]
         if m.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_conflict_frac"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+    if m.get("SQ_THREAD_CYCLES_VALU") and m.get("SQ_ACTIVE_INST_VALU"):
+        e["active_lane_frac"] = m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"])
     if "SQ_INSTS_MFMA" in m:
         e["mfma_insts_per_launch"] = m["SQ_INSTS_MFMA"]
         e["lds_insts_per_launch"] = m.get("SQ_INSTS_LDS", 0.0)

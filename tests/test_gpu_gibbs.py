@@ -147,15 +147,18 @@ def test_sweep_with_many_large_psi_rows(gpu, oracle, scale, P):
     g.close()
 
 
+@pytest.mark.parametrize("P", [64, 256])
 @pytest.mark.parametrize("N,nmax,scale", [(1, 1, 1.0), (15, 1, 1.0), (16, 3, 1.0), (17, 1, 1.0), (4097, 1, 1.0),
                                           (100003, 1, 1.0), (100003, 3, 1.0), (50000, 1, 8.0), (20011, 1, 0.0)])
-def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale):
-    """P = 64 sweeps run on kernels_sweep1.hip (X read once; rows outside the fast path -- attempts 0..3 all retries,
-    first series test open, |psi|/2 >= 1/t, n != 1 -- drawn by a second kernel) unless bl_set_sweep_mode(0) selects the two
-    streaming passes.  Same omega (the deferred rows' sampler is another instantiation: 1e-13), same X'Omega X up to
-    summation order, both next to the oracle; omega not requested gives the same X'Omega X bit for bit."""
+def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale, P):
+    """P = 64 sweeps run on kernels_sweep1.hip and P = 256 sweeps on kernels_sweep256.hip (X read once; rows outside the fast
+    path -- attempts 0..3 all retries, first series test open, |psi|/2 >= 1/t, n != 1 -- drawn by a second kernel) unless
+    bl_set_sweep_mode(0) selects the two streaming passes.  Same omega (P = 256: bit for bit where no row is deferred; the
+    deferred rows' sampler is another instantiation: 1e-13), same X'Omega X up to summation order, both next to the oracle;
+    omega not requested gives the same X'Omega X bit for bit."""
     from bayeslogit_amd import device as D
-    P = 64
+    if P == 256 and N > 60000:
+        N = 60003                              # (the oracle's O(N P^2) contraction)
     X, y, n = synth(N, P, 3 * N + nmax, nmax=nmax)
     beta0 = np.linspace(-1.0, 1.0, P) * scale
     out = {}
@@ -180,6 +183,7 @@ def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale):
     (w0, PP0, nd0), (w1, PP1, nd1) = out[0], out[1]
     assert nd0 == 0
     assert np.allclose(w1, w0, rtol=1e-13, atol=0)
+    assert (w1 != w0).sum() <= nd1             # a row the fast path settles gets the two passes' omega bit for bit
     assert np.array_equal(PP1, PP1.T)
     assert np.abs(PP1 - PP0).max() <= 1e-13 * np.abs(PP0).max()
     PPo, wo = oracle.sweep_partial(X, n, beta0, 31, 3, 123456789012)
@@ -756,3 +760,83 @@ def test_constrained_sweeps_two_kernels_same_bits(gpu, P):
             assert np.array_equal(out[1], out[0])
     finally:
         D.set_beta_sweeps(1)
+
+
+def test_same_handle_same_seed_twice_gives_the_same_bits(gpu):
+    """The P = 64 single-pass fall-back is chain state, not handle state: on rare-event-like data a chain's first 8 sweeps
+    take the single pass and the later ones the two passes (another summation order of X'Omega X).  A second chain on the
+    SAME handle -- bl_gibbs_chain_start, which bl_gibbs_run / run_stream call themselves -- must make the same choices:
+    X'Omega X of every sweep bit for bit, and the same beta history from run()."""
+    from bayeslogit_amd import device as D
+    N, P = 40000, 64
+    X, y, n = synth(N, P, 77)
+    beta0 = np.linspace(-1.0, 1.0, P) * 8.0
+    g = shard_of(X, y, n, gpu, seed=13, idx0=5)
+
+    def pass_over():
+        g.chain_start()
+        pps, counts = [], []
+        for s_ in range(10):
+            g.set_beta(beta0)
+            D.sweep_deferred_rows()
+            g.sweep_local(s_, None)
+            D.sync_status()
+            counts.append(D.sweep_deferred_rows())
+            pps.append(g.pp().cpu().numpy().copy())
+        return pps, counts
+
+    p1, c1 = pass_over()
+    p2, c2 = pass_over()
+    assert c1 == c2 and all(c > 0 for c in c1[:8]) and c1[8] == 0 and c1[9] == 0, (c1, c2)   # fell back after sweep 8, both times
+    for a, b in zip(p1, p2):
+        assert np.array_equal(a, b)
+    g.set_prior(np.zeros(P), np.eye(P))
+    h1 = g.run(12, 2, constrain=1)
+    h2 = g.run(12, 2, constrain=1)
+    assert np.array_equal(h1, h2) and np.all(np.isfinite(h1))
+    g.close()
+
+
+@pytest.mark.parametrize("P", [12, 100])
+def test_failed_cholesky_of_one_handle_does_not_stop_another(gpu, P):
+    """The dead-chain flag belongs to the handle: handle A's precision is not positive definite and its failure has not
+    been collected yet (step API, no sync) when handle B draws -- B's draw must be the one it makes alone.  The process-wide
+    status word still reports A's failure at the next bl_sync_status."""
+    import bayeslogit_amd as bl
+    from bayeslogit_amd import device as D
+    X, y, n = synth(8 * P, P, 3 + P)
+
+    def prepared(P0):
+        g = shard_of(X, y, n, gpu, seed=21)
+        g.set_prior(np.zeros(P), P0)
+        g.chain_start()
+        g.set_bp_local()
+        g.finish_bp()
+        g.set_beta(np.zeros(P))
+        g.sweep_local(0, None)
+        return g
+
+    alone = prepared(np.eye(P))
+    alone.draw_beta(0, 1)
+    D.sync_status()
+    want = alone.get_beta()
+    alone.close()
+    assert np.all(np.isfinite(want)) and np.any(want != 0.0)
+    bad, good = prepared(-50.0 * np.eye(P)), prepared(np.eye(P))
+    bad.draw_beta(0, 1)                      # fails on the device; nothing collected yet
+    good.draw_beta(0, 1)
+    with pytest.raises(bl.BayesLogitError) as ei:
+        D.sync_status()
+    assert "positive definite" in str(ei.value)
+    assert np.array_equal(good.get_beta(), want)
+    # the failed handle stays dead until its next chain starts; a new chain on it with a proper prior runs
+    bad.set_prior(np.zeros(P), np.eye(P))
+    bad.chain_start()
+    bad.set_bp_local()
+    bad.finish_bp()
+    bad.set_beta(np.zeros(P))
+    bad.sweep_local(0, None)
+    bad.draw_beta(0, 1)
+    D.sync_status()
+    assert np.array_equal(bad.get_beta(), want)
+    bad.close(), good.close()
