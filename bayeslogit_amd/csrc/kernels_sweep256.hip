@@ -16,15 +16,18 @@
 //     the two passes returns); the row weights go to LDS.  A row not settled by its four attempts, or whose first series
 //     test is open, or with |psi|/2 >= 1/t, or n_i != 1, enters its tile with weight 0 and goes to the workgroup's list in
 //     global memory; k_sweep_deferred256 draws those with the full sampler and gathers their rows of X again.
-//   * the draw costs wave 0's SIMD what ~40 matrix instructions per 4-row group cost (fp64 vector and matrix instructions
-//     do not overlap on this part), so the 528 matrix instructions of a group are dealt out unevenly: per SIMD (waves w and
-//     w + 4) 100 + the draw / 144 / 144 / 140 instead of 128 / 128 / 136 / 136.  The 16 x 16 upper triangle of cells (16-column
-//     chunks) is cut into the four diagonal 4 x 4 blocks D0..D3 (36 instructions) and, right of block-row I, column strips
-//     of 4 x 1 cells (16 instructions: four A operands against the four rotations of one chunk):
-//        wave 0: the draw + D3           wave 4: block-row 2, chunks 12..15
-//        wave 1: block-row 0, chunks 4..9     wave 5: block-row 1, chunks 8..10
-//        wave 2: block-row 0, chunks 10..15   wave 6: block-row 1, chunks 11..13
-//        wave 3: block-row 1, chunks 14, 15 + D1     wave 7: D0 + D2
+//   * fp64 vector and matrix instructions do not overlap on this part, so the draw is paid for in matrix-pipe time on wave 0's
+//     SIMD (waves w and w + 4 of a workgroup always share one: scripts/experiments/wave_simd_map.hip), and the 528 matrix
+//     instructions of a 4-row group are dealt out unevenly: per SIMD 100 + the draw / 144 / 144 / 140 instead of 128 / 128 /
+//     136 / 136.  The 16 x 16 upper triangle of cells (16-column chunks) is cut into the four diagonal 4 x 4 blocks D0..D3 (36
+//     instructions) and, right of block-row I, column strips of 4 x 1 cells (16 instructions: four A operands against the
+//     four rotations of one chunk):
+//        wave 0: the draw, nothing else          wave 4: block-row 2, chunks 12..15 + D3
+//        wave 1: block-row 0, chunks 4..9        wave 5: block-row 1, chunks 8..10
+//        wave 2: block-row 0, chunks 10..15      wave 6: block-row 1, chunks 11..13
+//        wave 3: block-row 1, chunks 14, 15 + D1 wave 7: D0 + D2
+//     (wave 0 with D3 beside the draw: 16.2 ms per 12.5e6-row shard against 15.7 -- a step waits for its slowest WAVE, and the
+//     attempt body is a long dependent chain; without any draw the loop takes 15.15 ms, k_xwx_q4_blk16 alone 16.0.)
 //   * a workgroup owns a contiguous range of tiles (its list of deferred rows lives in that range of two N-long arrays and
 //     cannot overflow; fixed summation order: PP is reproducible and exactly symmetric).
 //
@@ -47,7 +50,7 @@ constexpr int kRowB = 128 * kNC + 128;       // bytes per row of a tile (consecu
 constexpr int kRT = 16;                      // rows per tile
 constexpr int kTileB = kRT * kRowB;          // 34 816 bytes
 constexpr int kNBuf = 3;
-constexpr int kAccMax = 96;                  // accumulator doubles per lane of the widest role (six strips)
+constexpr int kAccMax = 100;                 // accumulator doubles per lane of the widest role (four strips + a diagonal block)
 constexpr int kSeg = 512;                    // deferred rows drawn at a time (their weights wait in LDS)
 
 // what a wave multiplies: NS strips (chunks J0 .. J0+NS-1 against block-row I) and ND diagonal blocks (D[0..ND))
@@ -55,11 +58,11 @@ struct Role { int I, J0, NS, ND, D0, D1; };
 __host__ __device__ constexpr Role role_of(int wave)
 {
   switch (wave) {
-    case 0: return Role{3, 12, 0, 1, 3, 3};
+    case 0: return Role{3, 12, 0, 0, 3, 3};
     case 1: return Role{0, 4, 6, 0, 0, 0};
     case 2: return Role{0, 10, 6, 0, 0, 0};
     case 3: return Role{1, 14, 2, 1, 1, 1};
-    case 4: return Role{2, 12, 4, 0, 0, 0};
+    case 4: return Role{2, 12, 4, 1, 3, 3};
     case 5: return Role{1, 8, 3, 0, 0, 0};
     case 6: return Role{1, 11, 3, 0, 0, 0};
     default: return Role{0, 0, 0, 2, 0, 2};
@@ -179,6 +182,10 @@ __device__ __forceinline__ void wave_main(const Ctx& cx, const int wave, const i
     return cx.nvec[row];
   };
   auto draw_tile = [&](int64_t j, int b, double nn) __attribute__((always_inline)) {
+#ifdef BL_S256_NODRAW            // timing experiment only (scripts/experiments): what the draw costs the tile loop
+    if (a == 0) cx.wt[b * kRT + 4 * gq + k] = 0.125 + 0.0 * nn;
+    return;
+#endif
     const char* tile = cx.tiles + b * kTileB;
     double psi = 0.0;
 #pragma unroll
@@ -333,11 +340,11 @@ template <bool GATHER>
 __device__ __forceinline__ void dispatch_roles(const Ctx& cx, int wave, int lane, double* slab, int& nDef, bool first = true)
 {
   switch (wave) {          // (a scalar: the waves branch apart once)
-    case 0: wave_main<0, 1, !GATHER, GATHER>(cx, 0, lane, slab, nDef, first); break;
+    case 0: wave_main<0, 0, !GATHER, GATHER>(cx, 0, lane, slab, nDef, first); break;
     case 1: wave_main<6, 0, false, GATHER>(cx, 1, lane, slab, nDef, first); break;
     case 2: wave_main<6, 0, false, GATHER>(cx, 2, lane, slab, nDef, first); break;
     case 3: wave_main<2, 1, false, GATHER>(cx, 3, lane, slab, nDef, first); break;
-    case 4: wave_main<4, 0, false, GATHER>(cx, 4, lane, slab, nDef, first); break;
+    case 4: wave_main<4, 1, false, GATHER>(cx, 4, lane, slab, nDef, first); break;
     case 5: wave_main<3, 0, false, GATHER>(cx, 5, lane, slab, nDef, first); break;
     case 6: wave_main<3, 0, false, GATHER>(cx, 6, lane, slab, nDef, first); break;
     default: wave_main<0, 2, false, GATHER>(cx, 7, lane, slab, nDef, first); break;
