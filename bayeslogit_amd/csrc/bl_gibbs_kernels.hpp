@@ -108,6 +108,8 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s);
 
 // dist = max_j |a_j - b_j| into *out (device double)
 void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hipStream_t s);
+// dst[i] = src[i * stride + off], i < n
+void launch_gather_stride(double* dst, const double* src, int64_t n, int stride, int off, hipStream_t s);
 // dst[j] = a[j] + (b ? b[j] : 0)
 void launch_vec_add(double* dst, const double* a, const double* b, int P, hipStream_t s);
 // dst = P0 * m0  (P x P times P)

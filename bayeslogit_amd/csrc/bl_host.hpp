@@ -34,6 +34,11 @@ int      sweep_single_pass();               // bl_set_sweep_mode / BL_SWEEP_SING
 int      beta_sweeps_kind();                // bl_diag_beta_sweeps / BL_BETA_SPLIT (default 1: row-split sweeps)
 unsigned long long* sweep_stats();          // device counters of the single-pass sweep (bl_diag_sweep_deferred)
 
+// host (pageable, caller-owned) -> device; large buffers go through pinned staging (host_state.hip).  Synchronous for
+// large copies (returns when the data is on the device), asynchronous on `s` for small ones -- as hipMemcpyAsync from
+// pageable memory is.
+hipError_t upload_staged(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
+
 #define BL_HIP_TRY(expr)                                                            \
   do {                                                                              \
     hipError_t _e = (expr);                                                         \
@@ -59,7 +64,7 @@ struct DevBuf {
   }
   hipError_t upload(const T* host, hipStream_t s = nullptr)
   {
-    return hipMemcpyAsync(p, host, sizeof(T) * n, hipMemcpyHostToDevice, s);
+    return upload_staged(p, host, sizeof(T) * n, s);
   }
   hipError_t download(T* host, hipStream_t s = nullptr) const
   {

@@ -602,11 +602,17 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   const uint64_t seed = bl::chain_key(blh::global_seed(), blh::next_epoch());   // bl_philox.hpp
   hipStream_t s = nullptr;
   const size_t PPn = (size_t)p * p;
-  blh::DevBuf<double> dX, dty, dn, dw, dbeta, dXB, dc, deta, done, dZ, db0, dP0, dm0, dkap, db1, dxoc;
+  const size_t wslot_n = (size_t)(n > 0 ? n : 1) * u;            // doubles of omega per kept sweep
+  // omega (N x (J-1) x samp in the caller's HOST memory) goes back sweep by sweep through a small device ring on a second
+  // stream while the next sweep runs (as bl_gibbs_run_stream does): device memory O(N J), not O(N J samp)
+  int K = (int)((int64_t)(256ll << 20) / (int64_t)(8 * wslot_n));
+  K = K < 2 ? 2 : (K > samp ? samp : K);
+  if (K < 1) K = 1;
+  blh::DevBuf<double> dX, dty, dn, dring, dbeta, dXB, dc, deta, done, dZ, db0, dP0, dm0, db1, dxoc, dyj;
   hipError_t e = dX.alloc((size_t)n * p);
   if (e == hipSuccess) e = dty.alloc((size_t)n * u);
   if (e == hipSuccess) e = dn.alloc(n);
-  if (e == hipSuccess) e = dw.alloc((size_t)n * u * samp);
+  if (e == hipSuccess) e = dring.alloc(wslot_n * K);
   if (e == hipSuccess) e = dbeta.alloc((size_t)p * u * samp);
   if (e == hipSuccess) e = dXB.alloc((size_t)n * (u + 1));
   if (e == hipSuccess) e = dc.alloc(n);
@@ -616,9 +622,9 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   if (e == hipSuccess) e = db0.alloc((size_t)p * u);
   if (e == hipSuccess) e = dP0.alloc(PPn * u);
   if (e == hipSuccess) e = dm0.alloc((size_t)p * u);
-  if (e == hipSuccess) e = dkap.alloc(n);
   if (e == hipSuccess) e = db1.alloc(p);
   if (e == hipSuccess) e = dxoc.alloc(p);
+  if (e == hipSuccess) e = dyj.alloc(n);
   if (e == hipSuccess) e = dX.upload(tXp);
   if (e == hipSuccess) e = dty.upload(typ);
   if (e == hipSuccess) e = dn.upload(np);
@@ -628,30 +634,43 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
   if (e == hipSuccess) e = done.upload(&one);
   if (e == hipSuccess) e = hipMemset(dXB.p, 0, sizeof(double) * (size_t)n * (u + 1));
   if (e == hipSuccess) e = hipMemset(dbeta.p, 0, sizeof(double) * (size_t)p * u * samp);
+  hipStream_t cs = nullptr;
+  std::vector<hipEvent_t> ev_done(K, nullptr), ev_copied(K, nullptr);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  for (int i = 0; e == hipSuccess && i < K; ++i) {
+    e = hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_copied[i], hipEventDisableTiming);
+  }
+  auto cleanup = [&]() {
+    if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    for (auto& ev : ev_done) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ev_copied) if (ev) (void)hipEventDestroy(ev);
+  };
   if (e != hipSuccess) {
     blh::set_error(std::string("mult_gibbs: ") + hipGetErrorString(e));
     printf("Aborting Gibbs sampler.\n");
+    cleanup();
     return;
   }
   bl_gibbs* h = nullptr;
   int rc = bl_gibbs_create(&h, n, p, 0, seed, s);
   if (rc == BL_OK) rc = bl_gibbs_set_data(h, dX.p, nullptr, dn.p);
   // y (U x N, category fastest) -> per-category rows for kappa: Z_j = X' (n (y_j - 1/2)), MultLogit.hpp:214-219
-  std::vector<double> yj((size_t)(n > 0 ? n : 1));
-  blh::DevBuf<double> dyj;
-  if (rc == BL_OK && dyj.alloc(n) != hipSuccess) rc = BL_ERR_HIP;
   for (int j = 0; rc == BL_OK && j < u; ++j) {
-    for (int64_t i = 0; i < n; ++i) yj[i] = typ[(size_t)i * u + j];
-    if (dyj.upload(yj.data()) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { rc = BL_ERR_HIP; break; }
+    blk::launch_gather_stride(dyj.p, dty.p, n, u, j, s);
     blk::launch_colsum(dX.p, dyj.p, dn.p, nullptr, nullptr, n, p, h->colws, dZ.p + (size_t)j * p, s);
     blk::launch_matvec(db0.p + (size_t)j * p, dP0.p + (size_t)j * PPn, dm0.p + (size_t)j * p, p, s);   // b0_j = P0_j m0_j
   }
   const blk::SweepPlan plan1 = blk::make_plan(n, 1, num_cus());
   const int total = burn + samp;   // burn+1 sweeps into slot 0, then samp-1 more (MultLogit.hpp:284,332)
-  for (int sw = 0; rc == BL_OK && sw < total; ++sw) {
+  std::vector<char> copied_once(K, 0);
+  for (int sw = 0; rc == BL_OK && e == hipSuccess && sw < total; ++sw) {
     const int slot = sw <= burn ? 0 : sw - burn;
+    const int rpos = slot % K;
     double* bslot = dbeta.p + (size_t)slot * p * u;
-    double* wslot = dw.p + (size_t)slot * n * u;
+    double* wslot = dring.p + (size_t)rpos * wslot_n;
+    if (copied_once[rpos]) e = hipStreamWaitEvent(s, ev_copied[rpos], 0);      // the ring slot's previous copy has left
+    if (e != hipSuccess) break;
     for (int j = 0; j < u; ++j) {
       const uint32_t epoch = (uint32_t)sw * (uint32_t)u + (uint32_t)j;
       double* bj = bslot + (size_t)j * p;
@@ -688,17 +707,31 @@ void mult_gibbs(double* wp, double* betap, double* typ, double* tXp, double* np,
       blk::launch_xbeta(dX.p, bj, n, p, dXB.p + (size_t)j * n, s);                 // XB_j = X beta_j
     }
     if (hipGetLastError() != hipSuccess) rc = BL_ERR_HIP;
+    // the sweep's omega is final in its slot once the slot will not be rewritten: burn-in rewrites slot 0 until sweep `burn`
+    if (rc == BL_OK && sw >= burn && n > 0) {
+      e = hipEventRecord(ev_done[rpos], s);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, ev_done[rpos], 0);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(wp + (size_t)slot * wslot_n, wslot, sizeof(double) * wslot_n, hipMemcpyDeviceToHost, cs);
+      if (e == hipSuccess) e = hipEventRecord(ev_copied[rpos], cs);
+      copied_once[rpos] = 1;
+    }
+  }
+  if (e != hipSuccess) {
+    blh::set_error(std::string("mult_gibbs: ") + hipGetErrorString(e));
+    rc = BL_ERR_HIP;
   }
   if (rc == BL_OK) rc = blh::collect_status(s);
   if (rc == BL_OK || rc == BL_ERR_SAMPLER) {
-    e = dw.download(wp);
-    if (e == hipSuccess) e = dbeta.download(betap);
+    e = dbeta.download(betap);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
     if (e != hipSuccess) blh::set_error(std::string("mult_gibbs: ") + hipGetErrorString(e));
   } else {
     printf("Error: %s\n", bl_last_error());
     printf("Aborting Gibbs sampler.\n");
   }
+  cleanup();
   bl_gibbs_destroy(h);
   *N = (int)n;
 }

@@ -4,7 +4,10 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 namespace {
 std::mutex g_mu;
@@ -105,6 +108,67 @@ uint32_t next_epoch() { return g_epoch.fetch_add(1); }
 int global_constrain() { return g_constrain.load(); }
 int sweep_single_pass() { return g_sweep_mode.load(); }
 int beta_sweeps_kind() { return g_beta_sweeps.load(); }
+// ---- host -> device upload of a caller-owned (pageable) buffer, as the .C boundary hands them over.
+// hipMemcpy from pageable memory reaches 24 GB/s on the MI355X box; copying 64 MB chunks into one of two pinned
+// staging buffers with four threads while the DMA engine drains the other reaches 54 GB/s
+// (scripts/experiments/h2d_staging.hip, profiles/r03_h2d_staging.txt; device -> host is 53 GB/s either way, and
+// hipHostRegister of the caller's pages costs more than it saves).  Small copies take the plain path.
+namespace {
+constexpr size_t kStageChunk = (size_t)64 << 20;
+constexpr int kStageThreads = 4;
+std::mutex g_stage_mu;
+char* g_stage[2] = {nullptr, nullptr};
+hipEvent_t g_stage_ev[2];
+hipStream_t g_stage_stream = nullptr;
+void par_memcpy(char* d, const char* s, size_t n)
+{
+  std::vector<std::thread> th;
+  const size_t per = ((n + kStageThreads - 1) / kStageThreads + 4095) & ~(size_t)4095;
+  for (int t = 1; t < kStageThreads; ++t) {
+    const size_t o = (size_t)t * per;
+    if (o >= n) break;
+    th.emplace_back([=] { memcpy(d + o, s + o, (o + per <= n) ? per : n - o); });
+  }
+  memcpy(d, s, per < n ? per : n);
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
+hipError_t upload_staged(void* dst_dev, const void* src_host, size_t bytes, hipStream_t user_stream)
+{
+  if (bytes < 2 * kStageChunk) return hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, user_stream);
+  std::lock_guard<std::mutex> l(g_stage_mu);
+  hipError_t e = hipSuccess;
+  if (!g_stage[0]) {
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      e = hipHostMalloc((void**)&g_stage[i], kStageChunk, 0);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g_stage_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {                                  // no pinned memory to be had: the plain path
+      g_stage[0] = nullptr;
+      return hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, user_stream);
+    }
+  }
+  // work already queued on the caller's stream may still read the destination: the copies start behind it
+  hipEvent_t before;
+  e = hipEventCreateWithFlags(&before, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(before, user_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(g_stage_stream, before, 0);
+  int b = 0;
+  for (size_t o = 0; o < bytes && e == hipSuccess; o += kStageChunk, b ^= 1) {
+    const size_t n = o + kStageChunk <= bytes ? kStageChunk : bytes - o;
+    e = hipEventSynchronize(g_stage_ev[b]);                 // the buffer's previous copy has left
+    if (e != hipSuccess) break;
+    par_memcpy(g_stage[b], (const char*)src_host + o, n);
+    e = hipMemcpyAsync((char*)dst_dev + o, g_stage[b], n, hipMemcpyHostToDevice, g_stage_stream);
+    if (e == hipSuccess) e = hipEventRecord(g_stage_ev[b], g_stage_stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(g_stage_stream);   // the staging buffers are free again; the data is on the device
+  (void)hipEventDestroy(before);
+  return e;
+}
+
 unsigned long long* sweep_stats() { return g_sweep_stats_dev; }
 unsigned long long* class_counts_slot() { return g_class_counts_dev + 8 * (g_class_slot.fetch_add(1) & 63u); }
 

@@ -762,6 +762,13 @@ __global__ void k_maxabsdiff(const double* a, const double* b, int P, double* ou
   if (threadIdx.x == 0) *out = sm[0];
 }
 
+// dst[i] = src[i * stride + off]  (row j of a U x N column-major matrix: mlogit's y_j, MultLogit.hpp:214-219)
+__global__ void k_gather_stride(double* __restrict__ dst, const double* __restrict__ src, int64_t n, int stride, int off)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[(size_t)i * stride + off];
+}
+
 __global__ void k_vec_add(double* dst, const double* a, const double* b, int P)
 {
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < P; j += gridDim.x * blockDim.x)
@@ -1045,6 +1052,14 @@ void launch_maxabsdiff(const double* a, const double* b, int P, double* out, hip
 {
   hipLaunchKernelGGL(k_maxabsdiff, dim3(1), dim3(kBlock), 0, s, a, b, P, out);
 }
+void launch_gather_stride(double* dst, const double* src, int64_t n, int stride, int off, hipStream_t s)
+{
+  if (n <= 0) return;
+  int64_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_gather_stride, dim3((unsigned)g), dim3(256), 0, s, dst, src, n, stride, off);
+}
+
 void launch_vec_add(double* dst, const double* a, const double* b, int P, hipStream_t s)
 {
   hipLaunchKernelGGL(k_vec_add, dim3(1), dim3(kBlock), 0, s, dst, a, b, P);

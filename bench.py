@@ -64,7 +64,7 @@ def parse():
                     help="rows of the problem on which a GPU chain and a CPU (oracle) chain are run on the same (X, y) and "
                          "their posterior mean/sd compared (0 = skip)")
     ap.add_argument("--post-samp", type=int, default=2000)
-    ap.add_argument("--mlogit-n", type=int, default=200_000, help="rows of the mlogit timing (P=32, J=5; 0 = skip)")
+    ap.add_argument("--mlogit-n", type=int, default=1_000_000, help="rows of the mlogit timing (P=32, J=5; 0 = skip) and of the combine timing (P=64)")
     ap.add_argument("--cpu-gibbs-n", type=int, default=1_000_000, help="rows of the timed CPU Gibbs sample (10 sweeps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the N>1 path on a 1-GPU box)")
     return ap.parse_args()
@@ -333,8 +333,12 @@ def cpu_hybrid(ncores, sample=2_000_000):
 
 
 def mlogit_bench(N, P=32, J=5, samp=20, burn=5):
-    """mlogit() as the R wrapper calls it (MultLogit.hpp:261-372): J-1 category sweeps per sweep."""
+    """mult_gibbs as the R wrapper's .C call reaches it (LogitWrapper.R:395; MultLogit.hpp:261-372: J-1 category sweeps per
+    sweep): host buffers in (X, y, n uploaded through pinned staging), omega of every kept sweep copied back through a
+    device ring while the next sweep runs.  The caller's buffers are allocated and touched BEFORE the timed call, as .C's
+    are (R copies every argument): a fresh numpy.zeros would put the host's first-touch page faults into the number."""
     import bayeslogit_amd as bl
+    from bayeslogit_amd import _lib
     rng = np.random.default_rng(20240006)
     X = rng.normal(size=(N, P)) / P ** 0.5
     X[:, -1] = 1.0
@@ -345,16 +349,50 @@ def mlogit_bench(N, P=32, J=5, samp=20, burn=5):
     y = np.zeros((N, J - 1))
     for j in range(J - 1):
         y[k == j, j] = 1.0
-    m0 = np.zeros((P, J - 1))
-    P0 = np.repeat((np.eye(P) * 0.01)[:, :, None], J - 1, axis=2)
+    del eta, cum
+    n = np.ones(N)
+    m0 = np.zeros((P, J - 1), order="F")
+    P0 = np.asfortranarray(np.repeat((np.eye(P) * 0.01)[:, :, None], J - 1, axis=2))
+    w = np.empty((samp, J - 1, N))
+    w.fill(0.0)
+    beta = np.zeros((samp, J - 1, P))
     bl.set_seed(20240007)
+    c_i = lambda v: ctypes.byref(ctypes.c_int(int(v)))
+    dp = lambda a: a.ctypes.data_as(_lib.c_dp)
     t0 = time.perf_counter()
-    out = bl.mlogit(y, X, None, m0, P0, samp=samp, burn=burn)
+    _lib.lib().mult_gibbs(dp(w), dp(beta), dp(y), dp(X), dp(n), dp(m0), dp(P0), c_i(N), c_i(P), c_i(J), c_i(samp), c_i(burn))
     dt = time.perf_counter() - t0
-    return {"workload": f"mlogit N={N}, P={P}, J={J}, burn {burn} + samp {samp} through the .C boundary (host upload of X, y; "
-                        "omega of every kept sweep copied back: N x (J-1) x samp doubles)",
+    bytes_in = 8.0 * (N * P + N * (J - 1) + N)
+    bytes_out = 8.0 * N * (J - 1) * samp
+    return {"workload": f"mult_gibbs N={N}, P={P}, J={J}, burn {burn} + samp {samp} through the .C boundary (host X, y, n in: "
+                        f"{bytes_in / 1e9:.2f} GB; omega of every kept sweep out: {bytes_out / 1e9:.2f} GB)",
             "seconds": dt, "sweeps_per_s_incl_host_transfers": (samp + burn) / dt,
-            "beta_err_max_last_sweep": float(np.abs(out["beta"][-1] - B).max())}
+            "category_sweeps_per_s": (samp + burn) * (J - 1) / dt,
+            "beta_err_max_last_sweep": float(np.abs(beta[-1].T - B).max()),
+            "omega_mean": float(w.mean())}
+
+
+def combine_bench(N=1_000_000, P=64):
+    """combine() (LogitWrapper.cpp:279-310 / Logit::compress, Logit.hpp:192-270: an O(N^2 P) list walk in the reference)
+    through the .C symbol at a size the replacement exists for: N rows of which a third repeat an earlier row."""
+    from bayeslogit_amd import _lib
+    rng = np.random.default_rng(20240008)
+    uniq = 2 * N // 3
+    base = rng.normal(size=(uniq, P))
+    pick = np.concatenate([np.arange(uniq), rng.integers(0, uniq // 4, N - uniq)])
+    rng.shuffle(pick)
+    X = np.ascontiguousarray(base[pick])
+    y = rng.uniform(size=N)
+    n = rng.integers(1, 5, N).astype(np.float64)
+    Nc = ctypes.c_int(N)
+    n_sum = float(n.sum())
+    dp = lambda a: a.ctypes.data_as(_lib.c_dp)
+    t0 = time.perf_counter()
+    _lib.lib().combine(dp(y), dp(X), dp(n), ctypes.byref(Nc), ctypes.byref(ctypes.c_int(P)))
+    dt = time.perf_counter() - t0
+    return {"workload": f"combine N={N}, P={P}, {N - uniq} rows repeat an earlier one; .C boundary (host buffers in and out)",
+            "rows_out": Nc.value, "rows_out_expected": uniq, "seconds": dt, "M_rows_per_s": N / dt / 1e6,
+            "n_total_preserved": bool(abs(float(n[:Nc.value].sum()) - n_sum) < 1e-9 * n_sum)}
 
 
 def gibbs_bench(N, P, sweeps, tag, rank, world, dev, D, DistGibbs, shard_range, chain=0):
@@ -704,6 +742,7 @@ def main():
     # mlogit through the .C boundary (host buffers in and out, omega of every sweep stored as the reference does)
     if not a.no_gibbs and rank == 0 and world == 1 and a.mlogit_n > 0:
         out["gibbs"]["mlogit"] = mlogit_bench(a.mlogit_n)
+        out["gibbs"]["combine"] = combine_bench(a.mlogit_n)
     # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
     if not a.no_c5:
         tag5 = "C5" if (world == 8 and a.c5_rows == 12_500_000) else \

@@ -840,3 +840,55 @@ def test_failed_cholesky_of_one_handle_does_not_stop_another(gpu, P):
     D.sync_status()
     assert np.array_equal(bad.get_beta(), want)
     bad.close(), good.close()
+
+
+def _combine_numpy(y, X, n):
+    """Logit::compress (Logit.hpp:192-270) restated with a sort: every row is folded into the FIRST row (index order) with
+    identical covariates, folds in index order  y_i <- (n_i/s) y_i + (n_j/s) y_j, n_i <- s = n_i + n_j; survivors keep
+    first-occurrence order.  O(N log N); checked against the oracle's literal O(N^2) list walk at small N below."""
+    N, P = X.shape
+    key = np.ascontiguousarray(X + 0.0).view(np.dtype((np.void, 8 * P))).ravel()     # + 0.0: -0.0 and 0.0 are one value
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    rep = first[inv]                                      # index of the first occurrence of each row's value
+    order = np.lexsort((np.arange(N), rep))               # groups by representative, members in index order
+    rs = rep[order]
+    start = np.r_[True, rs[1:] != rs[:-1]]
+    pos = np.arange(N) - np.maximum.accumulate(np.where(start, np.arange(N), 0))      # rank inside the group
+    yy, nn = y.copy(), n.copy()
+    for r in range(1, int(pos.max()) + 1):                # round r folds every group's r-th duplicate
+        j = order[pos == r]
+        i = rep[j]
+        s = nn[i] + nn[j]
+        yy[i] = (nn[i] / s) * yy[i] + (nn[j] / s) * yy[j]
+        nn[i] = s
+    keep = np.sort(first)
+    return yy[keep], X[keep], nn[keep]
+
+
+def test_combine_at_the_sizes_it_exists_for(gpu, oracle):
+    """The sort-based row merge replaces an O(N^2 P) list walk (Logit.hpp:192-270) that makes logit() unusable past
+    N ~ 1e5: parity at N = 1.2e6, P = 64 with a third of the rows duplicated up to five times, through the .C symbol
+    (host buffers in and out), against a numpy restatement that is itself held to the oracle's literal walk at N = 20 000."""
+    import time
+    import bayeslogit_amd as bl
+    rng = np.random.default_rng(12)
+    Xs = rng.integers(0, 3, size=(20000, 4)).astype(float)
+    ys, ns = rng.uniform(size=20000), rng.integers(1, 4, 20000).astype(float)
+    yo, Xo, no = oracle.combine(ys, Xs, ns)
+    yr, Xr, nr = _combine_numpy(ys, Xs, ns)
+    assert np.array_equal(Xr, Xo) and np.array_equal(nr, no) and np.array_equal(yr, yo)
+    N, P = 1_200_000, 64
+    base = rng.normal(size=(800_000, P))
+    pick = np.concatenate([np.arange(800_000), rng.integers(0, 150_000, N - 800_000)])     # rows < 150000 recur
+    rng.shuffle(pick)
+    X = base[pick]
+    y = rng.uniform(size=N)
+    n = rng.integers(1, 5, N).astype(float)
+    t0 = time.perf_counter()
+    c = bl.logit_combine(y, X, n)
+    dt = time.perf_counter() - t0
+    yr, Xr, nr = _combine_numpy(y, X, n)
+    assert c["X"].shape == Xr.shape and Xr.shape[0] == 800_000
+    assert np.array_equal(c["X"], Xr) and np.array_equal(c["n"], nr)
+    assert np.allclose(c["y"], yr, rtol=1e-13, atol=0)     # (the device contracts the fold's multiply-add; test_em_and_combine...)
+    assert dt < 20.0, dt                                  # (the reference's walk would need ~1e12 row comparisons)
