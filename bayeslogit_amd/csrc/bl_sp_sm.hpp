@@ -161,12 +161,14 @@ BL_HD SpPar sp_par(double n, double z, const double* __restrict__ vt, int& statu
   const double pig =
       1.0 - 0.5 * bl_exp(-0.5 * A1 * A1) * (erfcx_pos(A1 * kSpSqrtHalf) - erfcx_pos(A2 * kSpSqrtHalf));
   const double logn = bl_log(n);
-  const double lwl = lhal + n * (il - rt2rl + 0.5 * imd) + bl_log(pig);
+  const double lwl0 = lhal + n * (il - rt2rl + 0.5 * imd);                   // log wl = lwl0 + log pig
   // log wr, :220-222: Gamma(n) Q(n, x) = exp(-x) x^n CF(n, x), x = n rr md
   const double x = n * rr * md;
   const double cf = upper_gamma_cf(n, x, status);
-  const double lwr = lhar + 0.5 * (logn - kSpLog2Pi) + n * ir - x + bl_log(cf);
-  p.pl = 1.0 / (1.0 + bl_exp(lwr - lwl));                                    // :226-227
+  const double lwr0 = lhar + 0.5 * (logn - kSpLog2Pi) + n * ir - x;        // log wr = lwr0 + log cf
+  // wl / (wl + wr), :226-227, with the two factors that are not exponentials kept out of the exponent (two logs fewer):
+  // pig / (pig + exp(lwr0 - lwl0) cf)
+  p.pl = bl_div(pig, pig + bl_exp(lwr0 - lwl0) * cf);
   p.b = x;
   p.mdb = bl_div(md, x);
   p.lmdb = -(logn + bl_log(rr));                                           // log(md / (n rr md))

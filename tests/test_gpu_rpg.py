@@ -246,10 +246,90 @@ def test_full_size_C2_properties(gpu):
     assert torch.equal(x, x2) and x2.sum().item() == s1
 
 
-def test_full_size_C3_properties(gpu):
-    """BASELINE C3 (b in 1..50, z ~ N(0, sd^2 = 2)) at 2e7 draws: per-shape sample mean vs pg_m1."""
+def test_every_element_is_written_once_without_a_zeroing_launch(gpu, oracle):
+    """rpg_hybrid / rpg_alt / rpg_sp no longer zero x first: every element is written by exactly one kernel -- members by
+    their class's pass, the b <= 0 branch (LogitWrapper.cpp:159-161) by the first pass's scan, h == 0 and refused shapes
+    (rpg_alt / rpg_sp) by the scan, a two-task observation's zero by the scan before its tasks add.  Output buffers
+    pre-filled with NaN: none may survive, and the values are the oracle's; the class passes launched one by one
+    (bl_diag_rpg_hybrid_class_dev) write exactly their own members."""
+    import bayeslogit_amd as bl
     from bayeslogit_amd import device as D
-    n = 20_000_000
+    rng = np.random.default_rng(21)
+    n = 70001
+    h = rng.integers(1, 51, n).astype(float)
+    h[::13] = 0.0
+    h[1::29] = -2.0
+    h[2::31] = 0.37                      # sum of gammas
+    h[3::37] = 200.0                     # normal approximation
+    h[4::41] = 7.5
+    z = rng.normal(0, 1.5, n)
+    ht, zt = dev_t(h, gpu), dev_t(z, gpu)
+    x = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+    D.rpg_hybrid(ht, zt, seed=77, idx0=3, out=x)
+    D.sync_status()
+    xg = x.cpu().numpy()
+    assert not np.isnan(xg).any()
+    agree(xg, oracle.rpg_hybrid(n, h, z, 77, 0, 3), 1e-9)
+    assert np.all(xg[h <= 0] == 0.0)
+    # one pass at a time: its own class and nothing else
+    cls_of = np.where(h > 170, 5, np.where(h > 13, 4, np.where((h == 1) | (h == 2), 2, np.where(h > 1, 3, np.where(h > 0, 1, 0)))))
+    for cls in (1, 2, 3, 4, 5):
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        D.rpg_hybrid_class(ht, zt, cls, seed=77, idx0=3, out=y)
+        D.sync_status()
+        yg = y.cpu().numpy()
+        assert np.array_equal(~np.isnan(yg), cls_of == cls), cls
+        assert np.array_equal(yg[cls_of == cls], xg[cls_of == cls])
+    # rpg_alt / rpg_sp: h == 0 -> 0, a shape below 1 refused (flagged) -> 0, everything written
+    ha = rng.uniform(1.0, 40.0, n)
+    ha[::17] = 0.0
+    ha[5::19] = 0.5
+    for fn, ofn in ((D.rpg_alt, oracle.rpg_alt), (D.rpg_sp, lambda *a_: oracle.rpg_sp(*a_)[0])):
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device=gpu)
+        fn(dev_t(ha, gpu), zt, seed=78, idx0=9, out=y)
+        with pytest.raises(bl.BayesLogitError):
+            D.sync_status()                          # the refused shapes raise BL_ST_BAD_SHAPE
+        yg = y.cpu().numpy()
+        assert not np.isnan(yg).any() and np.all(yg[ha < 1.0] == 0.0)
+        href = np.where(ha < 1.0, 0.0, ha)
+        agree(yg, ofn(n, href, z, 78, 0, 9), 1e-9)
+
+
+def test_work_counts_of_the_draws(gpu):
+    """bl_diag_count_blocks_dev (bench.py's attempts per draw): an exact replay of the streams.  Devroye: every draw needs at
+    least one block and 1.1-1.6 on average at z ~ U(0,4); the saddle-point class's blocks are at least the iteration counts
+    rpg_sp returns (PolyaGammaSP::draw's `iter` counts its outer loop, an attempt is any pass of the body); class sizes
+    are those of rpg_hybrid's dispatch."""
+    from bayeslogit_amd import device as D
+    n = 200_000
+    z = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_unif(z, 0.0, 4.0, 5)
+    c = D.count_blocks(None, z, seed=6)
+    d = c["devroye"]
+    assert d["observations"] == n and d["draws"] == n and 1.1 * n < d["blocks"] < 1.6 * n
+    wz = c["devroye_wide_z"]
+    assert abs(wz["observations"] / n - (4.0 - 3.125) / 4.0) < 0.01           # |z|/2 >= 1/0.64
+    h = torch.empty(n, dtype=torch.float64, device=gpu)
+    D.fill_shape(h, 50, 5, epoch=1)
+    c = D.count_blocks(h, z, seed=6)
+    hh = h.cpu().numpy()
+    assert c["saddle_point"]["observations"] == int((hh > 13).sum())
+    assert c["alternating_series"]["observations"] == int(((hh > 2) & (hh <= 13)).sum())
+    assert c["devroye"]["observations"] == int((hh <= 2).sum()) and c["devroye"]["draws"] == int(hh[hh <= 2].sum())
+    it = torch.zeros(n, dtype=torch.int32, device=gpu)
+    sp = h > 13
+    D.rpg_sp(h[sp].contiguous(), z[sp].contiguous(), seed=6, iters=it[: int(sp.sum())])
+    D.sync_status()
+    # (the same shapes and z on other stream indices: compared in the mean, not row by row)
+    mean_iter = it[: int(sp.sum())].double().mean().item()
+    apd = c["saddle_point"]["blocks"] / c["saddle_point"]["draws"]
+    assert 1.0 <= mean_iter <= apd < 2.2, (mean_iter, apd)
+
+
+def test_full_size_C3_properties(gpu):
+    """BASELINE C3 (b in 1..50, z ~ N(0, sd^2 = 2)) at its full 1e8 draws: per-shape sample mean vs pg_m1."""
+    from bayeslogit_amd import device as D
+    n = 100_000_000
     z = torch.empty(n, dtype=torch.float64, device=gpu)
     h = torch.empty(n, dtype=torch.float64, device=gpu)
     D.fill_norm(z, 0.0, 2 ** 0.5, 20240001)
