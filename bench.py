@@ -676,6 +676,9 @@ def main():
         tq = {k: pmc_entry(k) for k in c3_kernels}
         per_kernel_traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tq.items()}
         have_all = n == 100_000_000 and per_kernel_traffic[c3_kernels[0]] and per_kernel_traffic[c3_kernels[1]]
+        # a class without members returns at once inside rpg_hybrid (C3: no b > 170, no b < 1); the committed per-kernel
+        # averages of those two kernels include the stand-alone passes of the branch table below, which do scan
+        c3_class_of = {"k_rpg_hybrid_class<5>": "normal_approximation", "k_rpg_hybrid_class<1>": "sum_of_gammas"}
         # per-branch rates: every class pass alone, event-timed, next to the replayed attempt counts
         branches = None
         if rank == 0:
@@ -721,7 +724,9 @@ def main():
                 "bound": "hbm", "limiter": "valu (scalar fp64 transcendental work; see the valu object)",
                 "achieved": gb3, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb3 / HBM_PEAK_GBS,
                 # the sum over ALL launches of one call (round 2 summed the two task kernels only)
-                "traffic": sum(v or 0.0 for v in per_kernel_traffic.values()) if have_all else None,
+                "traffic": (sum((v or 0.0) for k, v in per_kernel_traffic.items()
+                                if k not in c3_class_of or not branches or branches[c3_class_of[k]]["observations"] > 0)
+                            if have_all else None),
                 "traffic_per_kernel": per_kernel_traffic if have_all else None,
                 "traffic_source": c2_traffic_src, "traffic_measured_in_this_run": False,
                 "kernel_ms": k3, "algorithmic_bytes_per_launch": BYTES_PER_DRAW_VEC * n,

@@ -23,7 +23,10 @@ def test_contract_keys_and_types():
                    ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                    ("config", dict)]:
         assert k in d and isinstance(d[k], typ), k
-    assert "vs_baseline" in d and d["vs_baseline"] is None          # BASELINE.md publishes no number for this metric
+    # vs_baseline: value / the CPU baseline of the same run (the oracle on the box's host cores; the reference publishes no
+    # number at this size: BASELINE.md); the ratio to its one published PG(1,0) figure is a separate key
+    assert abs(d["vs_baseline"] - d["value"] / d["cpu_baseline"]["value"]) < 1e-9 * d["vs_baseline"]
+    assert abs(d["vs_published_pg10_serial"] - d["value"] / 2.4) < 1e-9 * d["value"] and "oracle" in d["vs_baseline_note"]
     assert d["metric"].startswith("PG draws/sec") and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
     assert "model" not in d["config"]
@@ -50,6 +53,21 @@ def test_roofline_and_cpu_baseline_objects():
     assert abs(gr["frac"] - gr["achieved"] / gr["peak"]) < 1e-12
     ch = g["chain"]
     assert ch["burn"] == 100 and ch["samp"] == 1000 and ch["max_abs_z"] < 5.0       # posterior means near the truth
+    # the exchange on its own, attempts per draw, the fp64-VALU rate, per-branch rates of C3, the C5 shard
+    ex = g["exchange"]
+    assert ex["bytes"] == 8 * 64 * 64 and ex["world_size"] == d["n_gpus"] and "allreduce_us" in ex
+    wk = r["work"]
+    assert 1.0 < wk["attempts_per_draw"] < 2.0 and 0.0 < wk["fp64_valu"]["frac"] < 1.0
+    assert abs(wk["fp64_valu"]["frac"] - wk["fp64_valu"]["achieved_tflops"] / wk["fp64_valu"]["peak_tflops"]) < 1e-12
+    br = d["mixed"]["branches"]
+    shares = sum(br[k]["share"] for k in ("saddle_point", "alternating_series", "devroye", "normal_approximation", "sum_of_gammas"))
+    assert abs(shares - 1.0) < 1e-6 and br["saddle_point"]["attempts_per_draw"] >= 1.0
+    mt = d["mixed"]["roofline"]
+    assert mt["traffic"] is None or mt["traffic"] >= mt["algorithmic_bytes_per_launch"]
+    c5 = d["gibbs_c5"]
+    assert c5["unit"] == "sweeps/s" and c5["roofline"]["bound"] == "mfma" and "12500000" in c5["workload"]
+    assert c5["roofline"]["traffic"] is None or c5["roofline"]["traffic"] < 1.1 * c5["roofline"]["algorithmic_bytes_per_launch"]
+    assert g["mlogit"]["sweeps_per_s_incl_host_transfers"] > 0 and g["combine"]["rows_out"] == g["combine"]["rows_out_expected"]
 
 
 def _bench_module(args):
