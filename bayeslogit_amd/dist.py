@@ -32,17 +32,31 @@ class ReplicaDivergence(RuntimeError):
 
 
 class DistGibbs:
-    def __init__(self, shard, group=None, check_every=0):
+    def __init__(self, shard, group=None, check_every=0, zero_copy=False):
         """check_every = k > 0: every k-th sweep verify that all ranks hold the same beta (one all-reduce of 2P
-        doubles); 0: only when verify_replicas() is called (run() calls it once at the end)."""
+        doubles); 0: only when verify_replicas() is called (run() calls it once at the end).
+        zero_copy: all-reduce the library's own P x P buffer in place (a torch view of foreign device memory) instead of a
+        torch-owned staging tensor (two device copies of P*P doubles per sweep: microseconds).  Off by default: the collective
+        libraries' stream bookkeeping is written for memory of torch's own allocator, and no multi-GPU node has run this yet."""
         self.shard = shard
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.check_every = int(check_every)
+        self.zero_copy = bool(zero_copy)
+        self._stage = {}
 
     def _all_reduce(self, t):
-        if self.world > 1:
+        if self.world <= 1:
+            return
+        if self.zero_copy:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        buf = self._stage.get(t.numel())
+        if buf is None:
+            buf = self._stage[t.numel()] = torch.empty(t.numel(), dtype=t.dtype, device=t.device)
+        buf.copy_(t)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(buf)
 
     def setup(self, m0, P0, beta0=None):
         s = self.shard

@@ -197,12 +197,14 @@ def test_single_pass_and_two_pass_sweeps_agree(gpu, oracle, N, nmax, scale, P):
         assert nd1 >= (n != 1).sum()
 
 
-def test_single_pass_gives_way_when_most_rows_are_deferred(gpu, oracle):
+@pytest.mark.parametrize("P", [64, 256])
+def test_single_pass_gives_way_when_most_rows_are_deferred(gpu, oracle, P):
     """Rare-event-like data (most |psi| > 3.1: the other left-piece sampler) leaves the single pass's fast path; the handle
     looks at its count of deferred rows after its 8th sweep and goes back to the two passes (bl_gibbs_sweep_local).  A
-    handle whose rows stay on the fast path does not.  omega is the oracle's either way."""
+    handle whose rows stay on the fast path does not.  omega is the oracle's either way.  (P = 64 and P = 256: the two
+    single-pass kernels share the policy.)"""
     from bayeslogit_amd import device as D
-    N, P = 40000, 64
+    N = 40000
     X, y, n = synth(N, P, 77)
     for scale, falls_back in ((8.0, True), (0.5, False)):
         beta0 = np.linspace(-1.0, 1.0, P) * scale
