@@ -176,7 +176,7 @@ BL_HD bool alt_attempt(AltLane& s, const AltPar& p, double u1, double u2, int& s
   } else {
     // r.igauss(mu, h^2) until <= trunc, :91-94
     const double mu = bl_div(h, p.Z), lam = h * h;
-    const double nu = qnorm(w);
+    const double nu = qnorm_t<true>(w);
     const double y = nu * nu;
     const double muy = mu * y;
     const double hml = bl_div(0.5 * mu, lam);

@@ -36,6 +36,7 @@
 #pragma once
 #include "bl_erfcx.hpp"
 #include "bl_fastmath.hpp"
+#include "bl_masscheb2.hpp"
 #include "bl_masspoly.hpp"
 #include "bl_philox.hpp"
 #include "bl_qnorm.hpp"
@@ -73,12 +74,22 @@ struct Pg1Lane {     // per lane
   double X;          // the accepted proposal when an attempt completes a draw
 };
 
+// true if any lane of the wavefront has `need` set (host build: the one caller)
+BL_HD bool pg1_any(bool need)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ballot(need) != 0ull;
+#else
+  return need;
+#endif
+}
+
 // mass_texpon(Z), PolyaGamma.cpp:65-80, rewritten (see header comment):
 //   exp(x0 - Z + log Phi(b)) = fz C erfcx((1 - tZ)/sqrt(2t)) / 2              (tZ <= 1)
 //                            = fz (exp(fz t - Z) - C erfcx((tZ - 1)/sqrt(2t))/2) (tZ > 1)
 //   exp(x0 + Z + log Phi(a)) = fz C erfcx((1 + tZ)/sqrt(2t)) / 2
-// with C = exp(t pi^2/8 - 1/(2t)).
-BL_HD double pg1_mass(double Z, double fz)
+// with C = exp(t pi^2/8 - 1/(2t)).  The literal erfcx form (two 28-term Chebyshev sums):
+BL_HD_COLD double pg1_mass_erfcx(double Z, double fz)
 {
   const double tz = kSmT * Z;
   const double ea = 0.5 * kMassC * erfcx_pos((1.0 + tz) * kSmInvSqrt2T);
@@ -87,7 +98,32 @@ BL_HD double pg1_mass(double Z, double fz)
     eb = 0.5 * kMassC * erfcx_pos((1.0 - tz) * kSmInvSqrt2T);
   else
     eb = bl_exp(fz * kSmT - Z) - 0.5 * kMassC * erfcx_pos((tz - 1.0) * kSmInvSqrt2T);
-  const double qdivp = 4.0 / kSmPi * fz * (ea + eb);
+  return 4.0 / kSmPi * fz * (ea + eb);
+}
+// For 1 <= tZ <= 26 (the mu <= t class up to |z| = 81) the two erfcx terms are one smooth function
+// H(Z) = C/2 [erfcx(k(tZ - 1)) - erfcx(k(tZ + 1))]: a 22-term Chebyshev series in r = s/(s + 4), s = tZ - 1
+// (bl_masscheb2.hpp, 1e-17 relative to what it is subtracted from; Clenshaw) -- a divide, 44 vector instructions and the one
+// exponential instead of two 28-term sums (round 3: the set-up was a quarter of the class's work).  Outside that range, and
+// for NaN, the erfcx form.
+BL_HD double pg1_mass(double Z, double fz)
+{
+  const double tz = kSmT * Z;
+  const bool mid = tz >= 1.0 && tz <= 1.0 + kMassCheb2SMax;
+  const double sv = tz - 1.0;
+  const double r = bl_div(sv, sv + kMassCheb2C);
+  const double x = fma(r, kMassCheb2Scale, -1.0), x2 = x + x;
+  double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+  for (int j = kMassCheb2N - 1; j >= 1; --j) {
+    const double bn = fma(x2, b1, kMassCheb2[j] - b2);
+    b2 = b1;
+    b1 = bn;
+  }
+  const double H = fma(x, b1, kMassCheb2[0] - b2);
+  double qdivp = 4.0 / kSmPi * fz * (bl_exp(fz * kSmT - Z) - H);
+  if (pg1_any(!mid)) {
+    if (!mid) qdivp = pg1_mass_erfcx(Z, fz);
+  }
   return 1.0 / (1.0 + qdivp);
 }
 
@@ -151,16 +187,6 @@ BL_HD_COLD int pg1_series(double X, double u)
     }
   }
   return 3;      // iteration cap (the reference loop is uncapped): accept and flag
-}
-
-// true if any lane of the wavefront has `need` set (host build: the one caller)
-BL_HD bool pg1_any(bool need)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __ballot(need) != 0ull;
-#else
-  return need;
-#endif
 }
 
 // Outcome of an attempt once X, the threshold A of u2 and the exponent of a_1/a_0 are known.
@@ -296,7 +322,7 @@ BL_HD bool pg1_attempt(Pg1Lane& s, const Pg1Par& p, double u1, double u2, int& s
   // mu <= t: inverse-Gaussian candidate from one normal, PolyaGamma.cpp:103-113 (divides and the square
   // root in bl_fastmath's short forms when FAST: <= 1 ulp from the IEEE sequences)
   const double mu = FAST ? bl_div(1.0, p.Z) : 1.0 / p.Z;
-  double Y = qnorm(w);
+  double Y = qnorm_t<FAST>(w);
   Y *= Y;
   const double half_mu = 0.5 * mu;
   const double mu_Y = mu * Y;

@@ -202,7 +202,7 @@ BL_HD bool sp_attempt(SpLane& s, const SpPar& p, const double* __restrict__ vt, 
   if (left) {
     // rtigauss(mu, n, md), :244: mu <= md always (mu <= xl), so r.igauss until <= md, :69-73
     const double mu = p.mu;
-    const double nu = qnorm(w);
+    const double nu = qnorm_t<true>(w);
     const double y = nu * nu;
     const double muy = mu * y;
     const double hml = bl_div(0.5 * mu, n);
