@@ -80,8 +80,8 @@ BL_HD_COLD AltQ alt_q_general(double h, double x)
 {
   int st = 0;
   const double lg = lgamma(h);
-  const double q = exp(-x + h * log(x) - lg) * upper_gamma_cf(h, x, st);
-  return AltQ{q, lg + log(h), st};
+  const double q = bl_exp(-x + h * bl_log(x) - lg) * upper_gamma_cf(h, x, st);
+  return AltQ{q, lg + bl_log(h), st};
 }
 
 BL_HD AltPar alt_par(double h, double z, double t, int& status)
@@ -122,7 +122,7 @@ BL_HD AltPar alt_par(double h, double z, double t, int& status)
     if (!integer_h) { q = g.q; lg1 = g.lg1; status |= g.status; }
   }
   const double wr = bl_exp(h * (kAltLogHalfPi - p.lfz)) * q;
-  p.p = wr / (wr + wl);                                      // :131
+  p.p = bl_div(wr, wr + wl);                                 // :131
   p.R = bl_div(t, h * h);
   // Dagpunar (Code/R/Ch.R:83-114): a = h, b = t fz; a == 1: the exponential, :88-89
   if (h == 1.0) {

@@ -5,6 +5,7 @@
 // Clenshaw's recurrence: no exp, no log.  Host- and device-callable so that the same
 // code is unit-tested on the CPU (tests/host_harness) and runs in the kernels.
 #pragma once
+#include "bl_fastmath.hpp"
 #include "bl_portable.hpp"
 
 namespace bl {
@@ -23,7 +24,8 @@ BL_HD double erfcx_pos(double x)
     1.0006151438958986636e-16, -2.0526637756950822749e-18, -5.6034549938209255408e-18,
     -6.1914971215037826687e-19
   };
-  const double t = (x - 3.0) / (x + 3.0);
+  const double t = bl_div(x - 3.0, x + 3.0);      // (the IEEE division sequence is ~30 instructions on gfx950; two of them were
+                                                  // most of this function)
   const double t2 = 2.0 * t;
   double b1 = 0.0, b2 = 0.0;
 #pragma unroll
@@ -32,7 +34,7 @@ BL_HD double erfcx_pos(double x)
     b2 = b1;
     b1 = b0;
   }
-  return (t * b1 - b2 + c[0]) / (1.0 + 2.0 * x);
+  return bl_div(t * b1 - b2 + c[0], 1.0 + 2.0 * x);
 }
 
 // exp(t pi^2/8 - 1/(2t)) at the Devroye truncation point t = 0.64 (see pg1_mass)

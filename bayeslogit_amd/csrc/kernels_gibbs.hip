@@ -14,6 +14,7 @@
 //     kernel k_xwx_mfma_big (128 or 256 columns); generic kernels (k_psi_omega + k_xwx_tiles) above that.
 //   * fixed-order reductions (no float atomics): every bit of PP is reproducible.
 //   * k_beta: the P x P stage (Cholesky, solves, both beta draws) in one workgroup.
+#include "bl_dpp.hpp"
 #include "bl_gibbs_kernels.hpp"
 #include <stdlib.h>
 #include "bl_host.hpp"
@@ -237,10 +238,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_psi_omega_nb(const double* __rest
         double part = 0.0;
 #pragma unroll
         for (int q = 0; q < NB; ++q) part += xg[q] * bq[q];
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);
-        part += __shfl_xor(part, 8);
+        part = row16_allsum(part);          // (bl_dpp.hpp: the xor butterfly's bits, without LDS)
         psi = (c == g) ? part : psi;
       }
       const int slot = t0 + 4 * c + k;          // the row whose psi this lane kept

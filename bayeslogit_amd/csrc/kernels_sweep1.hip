@@ -41,6 +41,7 @@
 //
 // psi and omega are those of the two-pass kernels (omega to the last bits: the deferred rows' sampler is another
 // instantiation of the same header); PP differs in summation order only (fixed order: reproducible).
+#include "bl_dpp.hpp"
 #include "bl_gibbs_kernels.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_sm.hpp"
@@ -245,10 +246,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
       double part = 0.0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) part += xg[q] * bq[q];
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
+      part = row16_allsum(part);          // (bl_dpp.hpp: the xor butterfly's bits, without LDS)
       psi = (gq == g) ? part : psi;
     }
     return psi;

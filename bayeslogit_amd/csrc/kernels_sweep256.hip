@@ -34,6 +34,7 @@
 // omega is that of the two passes to the last bit; PP differs in summation order only.
 #include <type_traits>
 
+#include "bl_dpp.hpp"
 #include "bl_gibbs_kernels.hpp"
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_sm.hpp"
@@ -198,10 +199,7 @@ __device__ __forceinline__ void wave_main(const Ctx& cx, const int wave, const i
         part += v.x * bq[2 * h];
         part += v.y * bq[2 * h + 1];
       }
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
+      part = row16_allsum(part);          // (bl_dpp.hpp: the xor butterfly's bits, without LDS)
       psi = (gq == g) ? part : psi;
     }
     const int64_t row = 16 * (cx.t0 + j) + 4 * gq + k;               // the row this lane's quad draws
