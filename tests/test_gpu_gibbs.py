@@ -894,3 +894,36 @@ def test_combine_at_the_sizes_it_exists_for(gpu, oracle):
     assert np.array_equal(c["X"], Xr) and np.array_equal(c["n"], nr)
     assert np.allclose(c["y"], yr, rtol=1e-13, atol=0)     # (the device contracts the fold's multiply-add; test_em_and_combine...)
     assert dt < 20.0, dt                                  # (the reference's walk would need ~1e12 row comparisons)
+
+
+@pytest.mark.parametrize("scale", [25.0, 3.0])
+def test_p256_single_pass_with_more_deferred_rows_than_a_segment(gpu, scale):
+    """k_sweep_deferred256 draws a workgroup's deferred rows 512 at a time; with 400 000 rows over 256 workgroups and most rows
+    outside the fast path (|psi| large, n up to 3) every workgroup has several segments, whose sums continue from the slab the
+    last one wrote.  Single pass against the two passes on the GPU: omega to 1e-13 (the deferred rows' sampler is another
+    instantiation of the same header), X'Omega X to summation order; the partly deferred case as well."""
+    from bayeslogit_amd import device as D
+    N, P = 400_000, 256
+    rng = np.random.default_rng(5)
+    X = torch.as_tensor(rng.standard_normal((N, P)) / np.sqrt(P), dtype=torch.float64, device=gpu)
+    n = torch.as_tensor(rng.integers(1, 4, N).astype(float), device=gpu)
+    y = torch.zeros(N, dtype=torch.float64, device=gpu)
+    beta0 = np.linspace(-1.0, 1.0, P) * scale
+    out = {}
+    try:
+        for mode in (0, 1):
+            D.set_sweep_mode(bool(mode))
+            g = D.GibbsShard(X, y, n, seed=77, idx0=10**10)
+            g.set_beta(beta0)
+            w = torch.full((N,), -1.0, dtype=torch.float64, device=gpu)
+            D.sweep_deferred_rows()
+            g.sweep_local(5, w)
+            D.sync_status()
+            out[mode] = (w.cpu().numpy(), g.pp().cpu().numpy().reshape(P, P).copy(), D.sweep_deferred_rows())
+            g.close()
+    finally:
+        D.set_sweep_mode(True)
+    (w0, PP0, _), (w1, PP1, nd) = out[0], out[1]
+    assert nd > 0.6 * N                                   # n != 1 alone defers two thirds of the rows: > 1 000 per workgroup
+    assert np.all(w1 > 0) and np.allclose(w1, w0, rtol=1e-13, atol=0)
+    assert np.array_equal(PP1, PP1.T) and np.abs(PP1 - PP0).max() <= 1e-13 * np.abs(PP0).max()
