@@ -68,3 +68,26 @@ def test_d1to4_is_the_series_gap_at_the_truncation_point(oracle):
             gap += (-1) ** (n + 1) * a
             e *= q2
         assert abs(gap / dd - 1) < 2e-9
+
+
+def test_H11_normal_approximation_variance_is_ill_conditioned_at_small_z(oracle):
+    """Hazard H11 (found by a randomised soak in round 3): above b = 170 rpg_hybrid draws N(pg_m1, pg_m2 - pg_m1^2)
+    (LogitWrapper.cpp:143-146), and jj_m2's (tanh z - z)/z^3 (PolyaGamma.cpp:221-231) cancels for 1e-12 < z <~ 1e-3 -- the
+    series branch only starts at z <= 1e-12.  The literal formula, which the oracle restates and the kernels run, loses digits
+    like 1e-16/z^2: at |z| = 2e-6 the variance is off by 4e-5 relative, and WHICH way depends on the last bit of tanh, so two
+    correct libms (glibc here, ocml on the GPU) give draws that differ by 1e-5 there.  Not a parity failure: the reference's own
+    output is rounding noise in that window.  GPU-vs-oracle comparisons of the b > 170 class keep |z| >= 0.01."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    L = oracle.lib()
+    b = 400.0
+    err = {}
+    for z in (2e-6, 2e-4, 2e-2, 0.2):
+        m1, m2 = L.bl_pg_m1(b, z), L.bl_pg_m2(b, z)
+        Z = mp.mpf(z) / 2
+        j1 = b * mp.tanh(Z) / Z
+        j2 = (b + 1) * b * (mp.tanh(Z) / Z) ** 2 + b * ((mp.tanh(Z) - Z) / Z ** 3)
+        exact = j2 / 16 - (j1 / 4) ** 2
+        err[z] = float(abs((m2 - m1 * m1) - exact) / exact)
+    assert err[0.2] < 1e-12 and err[2e-2] < 1e-10              # well conditioned where the samplers' data live
+    assert 1e-7 < err[2e-6] < 1e-2 and err[2e-4] > 1e-10        # the window: digits lost like 1e-16 / z^2
