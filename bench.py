@@ -70,27 +70,6 @@ def parse():
     return ap.parse_args()
 
 
-class c_stdout_to_stderr:
-    """The .C entry points print the reference's messages ("Warning: data was combined!", LogitWrapper.cpp / Logit.hpp:248-251)
-    through C stdio on stdout; bench.py's stdout carries ONE JSON line.  Inside this context file descriptor 1 is stderr
-    (C buffers flushed on both edges), so such messages cannot land before -- or, flushed at exit, after -- the line."""
-
-    def __enter__(self):
-        self._libc = ctypes.CDLL(None)
-        sys.stdout.flush()
-        self._libc.fflush(None)
-        self._saved = os.dup(1)
-        os.dup2(2, 1)
-        return self
-
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        self._libc.fflush(None)
-        os.dup2(self._saved, 1)
-        os.close(self._saved)
-        return False
-
-
 def launcher_cmd(argv, nproc, port):
     """The command a plain `python bench.py --gpus N` (N > 1, no WORLD_SIZE) starts: the driver's own launch line
     (one rank per GPU, rendezvous on 127.0.0.1) with bench.py's arguments passed through unchanged."""
@@ -595,6 +574,12 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a, sys.argv[1:]))          # before anything below touches the GPU
+    # stdout carries ONE JSON line and nothing else: from here on file descriptor 1 is stderr (library chatter -- gloo prints
+    # its rank connections on stdout -- and the .C entry points' C-level messages go there), and the line is written to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -767,9 +752,8 @@ def main():
                                    shard_range, chain=a.gibbs_chain)
     # mlogit through the .C boundary (host buffers in and out, omega of every sweep stored as the reference does)
     if not a.no_gibbs and rank == 0 and world == 1 and a.mlogit_n > 0:
-        with c_stdout_to_stderr():
-            out["gibbs"]["mlogit"] = mlogit_bench(a.mlogit_n)
-            out["gibbs"]["combine"] = combine_bench(a.mlogit_n)
+        out["gibbs"]["mlogit"] = mlogit_bench(a.mlogit_n)
+        out["gibbs"]["combine"] = combine_bench(a.mlogit_n)
     # C5: N = 1e8, P = 256 over 8 GPUs = 12.5e6 rows (25.6 GB) per GPU; run here with that shard per rank
     if not a.no_c5:
         tag5 = "C5" if (world == 8 and a.c5_rows == 12_500_000) else \
@@ -812,10 +796,13 @@ def main():
                 cg["posterior"]["cpu_side"] = "oracle (repo restatement), parity to the reference binary unpinned"
                 out["gibbs"]["posterior_vs_cpu"] = cg["posterior"]
 
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -18,6 +18,31 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (no WORLD_SIZE): bench.py starts its two ranks as children (gloo here: both
+    on the box's one GPU) and rank 0 prints ONE JSON line with n_gpus = 2, the Gibbs rows split over the ranks, the exchange
+    timed alone.  Reduced sizes: the plumbing is what is tested.  First in this module: the child processes are started before
+    this process has touched the GPU."""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--draws", "200000", "--mixed-steps", "1", "--gibbs-n", "40000", "--gibbs-sweeps", "2", "--gibbs-chain", "0",
+           "--no-cpu", "--mlogit-n", "0", "--c5-rows", "8192", "--c5-sweeps", "1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]                      # stdout is the one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["metric"].startswith("PG draws/sec") and d["value"] > 0
+    g = d["gibbs"]
+    assert "rows sharded over 2 GPU(s)" in g["workload"] and g["exchange"]["world_size"] == 2
+    assert g["exchange"]["backend"] == "gloo" and g["exchange"]["allreduce_us"] > 0
+    assert d["gibbs_c5"]["exchange"]["bytes"] == 8 * 256 * 256 and "cpu_baseline" not in d
+
+
 def test_two_ranks_on_the_real_shard(tmp_path):
     import torch
     if torch.cuda.device_count() < 1:                  # counting devices does not initialise the GPU

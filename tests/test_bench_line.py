@@ -97,6 +97,7 @@ def test_launcher_starts_the_ranks_as_children_before_any_gpu_call(monkeypatch):
     k = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[k + 1:] == args                                   # everything after the script is bench.py's own line
     seen = {}
+    before = torch.cuda.is_initialized()                         # True only when an earlier GPU test of this process did it
 
     def fake_call(c, env=None):
         seen["cmd"], seen["env"] = c, env
@@ -112,7 +113,7 @@ def test_launcher_starts_the_ranks_as_children_before_any_gpu_call(monkeypatch):
         raise AssertionError("main() returned instead of exiting with the children's code")
     except SystemExit as e:
         assert e.code == 7                                       # a failing child fails the parent
-    assert seen["gpu_initialised"] is False
+    assert seen["gpu_initialised"] is before                     # main() itself touched no GPU before handing over
     assert seen["cmd"][seen["cmd"].index(os.path.join(ROOT, "bench.py")) + 1:] == args
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in seen["env"]
     # RCCL needs one GPU per rank: without them the launcher refuses (rc 2) instead of starting ranks that cannot run
