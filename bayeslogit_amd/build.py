@@ -17,7 +17,10 @@ LIB = os.path.join(HERE, "libbayeslogit_hip.so")
 SOURCES = ["host_state.hip", "kernels_pg.hip", "kernels_tasks.hip", "kernels_gibbs.hip", "kernels_sweep1.hip", "kernels_sweep256.hip", "kernels_xwx4.hip", "kernels_beta.hip", "capi_gibbs.hip", "combine.hip"]
 # per-file flags (see the head of the file named)
 EXTRA = {"kernels_tasks.hip": ["-mllvm", "-disable-machine-licm"], "kernels_pg.hip": ["-mllvm", "-disable-machine-licm"],
-         "kernels_beta.hip": ["-mllvm", "-disable-machine-licm"], "kernels_sweep1.hip": ["-mllvm", "-disable-machine-licm"],
+         # (kernels_beta: the 16-double register vectors of the one-wavefront dense routines are allocas until the AMDGPU pass that
+         # turns allocas into vectors, whose default budget is a quarter of the registers: the rest would go to scratch)
+         "kernels_beta.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-promote-alloca-to-vector-vgpr-ratio=1"],
+         "kernels_sweep1.hip": ["-mllvm", "-disable-machine-licm"],
          "kernels_sweep256.hip": ["-mllvm", "-disable-machine-licm"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

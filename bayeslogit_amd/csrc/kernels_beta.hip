@@ -588,12 +588,11 @@ __device__ __forceinline__ double beta_stream_unif(uint64_t seed, uint32_t epoch
 
 constexpr int kRec = 20;   // doubles per pre-generated tnorm record: 4 attempts x (ua, log ua, log ub, normal) + (u8,0,0,0)
 
-// ---- single-wavefront dense kernels on LDS matrices (P <= 64, lane = column or row) ----
+// ---- single-wavefront dense kernels (P <= 64) ----
 // One wave needs no s_barrier: LDS operations of a wave execute in program order, so a
 // wave-level scheduling fence between a phase's writes and the next phase's reads is enough.
 // (Workgroup versions paid two or three barriers per column, ~1.4 us per column measured, and are gone.)  In the
-// constrained draw these leave the other three waves free to generate the draw's random input, build the scan
-// tables and solve for mP at the same time.
+// constrained draw these leave the other waves free to build the scan tables and solve for mP at the same time.
 #define WAVE_SYNC()                                        \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -606,136 +605,144 @@ __device__ __forceinline__ double bcast_f64(double v, int l)
                           __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// A = U'U in place (upper triangle holds U); lane j owns column j.  Same operation order per
-// element as the reference's LAPACK-style column Cholesky (subtractions in ascending k).  The
-// pivot row is passed between lanes by readlane, so the trailing update touches LDS only for the
-// lane's own column (independent addresses: the loads of several rows are in flight together).
-__device__ bool w_chol_upper(double* A, int P, int ld, int lane)
+// ---- the dense routines of one wavefront, P <= 64, matrix rows in registers (round 3) ----
+// What one wavefront alone on its SIMD pays (scripts/experiments/wave_issue_probe.hip, shader cycles): 4.7 per fp64 FMA,
+// dependent or not; 14.5 - 20 per FMA whose operand comes by two v_readlane into a scalar pair; 114 for an LDS write and
+// the read behind it; 7 to ISSUE a broadcast ds_read_b128 (3.5 a double: the reads of a wave do not overlap its own
+// FMAs, they queue in front of them); 190 for a square root and a divide; 16 for an indexed register read; a taken branch
+// tens.  So: the row of the matrix in registers, the pivot's multipliers through ONE LDS slot read back as broadcasts
+// twelve reads deep, no branch tree, no branch at all inside the pivot loops.
+//
+// A register array is not addressable by a run-time index; a 16-double vector is (s_set_gpr_idx): four of them hold the row,
+// the wave-uniform k picks the element (two moves against a 64-way branch tree's 340 cycles).
+typedef double d16 __attribute__((ext_vector_type(16)));
+// (four named vectors, neither an array nor a struct of them: only then does each stay a register tuple; and no branch
+// inside a loop that updates them: at a join the compiler copies whole vectors.  Hence the PHASES below: the pivots of one
+// quarter form one loop whose body is straight-line code over the quarters still live.)
+template <int Q, typename F>
+__device__ __forceinline__ void fill_quarter(d16& v, F&& f)
 {
-  for (int k = 0; k < P; ++k) {
-    const double akk = L_(A, k, k);
-    if (!(akk > 0.0)) return false;
-    const double d = sqrt(akk);
-    double ukj = 0.0;
-    if (lane > k && lane < P) {
-      ukj = L_(A, k, lane) / d;
-      L_(A, k, lane) = ukj;
-    }
-    if (lane == k) L_(A, k, k) = d;
-    double* col = A + lane * ld;
-    int i = k + 1;
-    for (; i + 3 < P; i += 4) {
-      const double u0 = bcast_f64(ukj, i), u1 = bcast_f64(ukj, i + 1), u2 = bcast_f64(ukj, i + 2), u3 = bcast_f64(ukj, i + 3);
-      if (lane < P) {
-        const double a0 = col[i], a1 = col[i + 1], a2 = col[i + 2], a3 = col[i + 3];
-        if (lane >= i) col[i] = a0 - u0 * ukj;
-        if (lane >= i + 1) col[i + 1] = a1 - u1 * ukj;
-        if (lane >= i + 2) col[i + 2] = a2 - u2 * ukj;
-        if (lane >= i + 3) col[i + 3] = a3 - u3 * ukj;
-      }
-    }
-    for (; i < P; ++i) {
-      const double u0 = bcast_f64(ukj, i);
-      if (lane >= i && lane < P) col[i] -= u0 * ukj;
-    }
-    WAVE_SYNC();
-  }
-  return true;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) v[jj] = f(16 * Q + jj);
 }
-
-// S = L L' in place (lower triangle holds L, strict upper zeroed); lane i owns row i.
-__device__ bool w_chol_lower(double* S, int P, int ld, int lane)
+#define BL_FILL_ROW(q0, q1, q2, q3, f) (fill_quarter<0>(q0, f), fill_quarter<1>(q1, f), fill_quarter<2>(q2, f), fill_quarter<3>(q3, f))
+template <int Q>
+__device__ __forceinline__ d16& quarter_of(d16& q0, d16& q1, d16& q2, d16& q3)
 {
-  for (int k = 0; k < P; ++k) {
-    const double akk = L_(S, k, k);
-    if (!(akk > 0.0)) return false;
-    const double d = sqrt(akk);
-    double lik = 0.0;
-    if (lane > k && lane < P) {
-      lik = L_(S, lane, k) / d;
-      L_(S, lane, k) = lik;
-    }
-    if (lane == k) L_(S, k, k) = d;
-    int j = k + 1;
-    for (; j + 3 < P; j += 4) {
-      const double l0 = bcast_f64(lik, j), l1 = bcast_f64(lik, j + 1), l2 = bcast_f64(lik, j + 2), l3 = bcast_f64(lik, j + 3);
-      if (lane < P) {
-        const double a0 = L_(S, lane, j), a1 = L_(S, lane, j + 1), a2 = L_(S, lane, j + 2), a3 = L_(S, lane, j + 3);
-        if (lane >= j) L_(S, lane, j) = a0 - lik * l0;
-        if (lane >= j + 1) L_(S, lane, j + 1) = a1 - lik * l1;
-        if (lane >= j + 2) L_(S, lane, j + 2) = a2 - lik * l2;
-        if (lane >= j + 3) L_(S, lane, j + 3) = a3 - lik * l3;
-      }
-    }
-    for (; j < P; ++j) {
-      const double l0 = bcast_f64(lik, j);
-      if (lane >= j && lane < P) L_(S, lane, j) -= lik * l0;
-    }
-    WAVE_SYNC();
-  }
-  for (int j = 1; j < P; ++j)
-    if (lane < j && lane < P) L_(S, lane, j) = 0.0;
-  WAVE_SYNC();
-  return true;
+  if constexpr (Q == 0) return q0;
+  else if constexpr (Q == 1) return q1;
+  else if constexpr (Q == 2) return q2;
+  else return q3;
 }
-
-// Register-resident Cholesky on one wavefront (P <= 64): lane i keeps row i of the (upper) triangle in 64
-// registers, so a step touches LDS only to pass the pivot row around (one 64-double buffer), not to update
-// the trailing matrix.  Same arithmetic as w_chol_upper / w_chol_lower -- u_kj = a_kj / sqrt(a_kk), then
-// a_ij -= u_ki u_kj, k ascending (a product of the same two numbers either way round) -- so the factor is
-// bit-identical; LOWER = false: A = U'U, reads and writes the upper triangle of M; LOWER = true: M = L L', reads
-// the lower triangle of M (row i of the transposed problem is column i of the lower triangle), writes L = U'
-// into it and zeroes the strict upper triangle.  buf: 64 doubles of LDS, 16-byte aligned.  Measured in k_beta64: 65 us each
-// against 130 for w_chol_upper / w_chol_lower.
-template <bool LOWER>
-__device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
+// Broadcast reads of LDS with the order of issue spelled out.  Left to the scheduler, three reads are in flight and a read
+// takes ~100 cycles to come back: 33 cycles per pair of columns against the 9.4 of its two FMAs (and the scheduling
+// builtins serialised it altogether).  So: chunks of eight doubles (four reads), three chunks in flight -- twelve of the
+// fifteen the counter can tell apart --, each waited for by count (LDS returns in order).
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct Bc8 {
+  d2 a, b, c, d;
+};
+template <bool ALIGNED, int OFF>      // OFF: in doubles from addr
+__device__ __forceinline__ void bcast8_issue(Bc8& t, unsigned addr)
 {
-  double r[64];
-#pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const bool in = lane < P && j < P && j >= lane;
-    r[j] = in ? (LOWER ? L_(M, j, lane) : L_(M, lane, j)) : 0.0;
+  if constexpr (ALIGNED)
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(t.a), "=&v"(t.b), "=&v"(t.c), "=&v"(t.d)
+                 : "v"(addr), "n"(8 * OFF), "n"(8 * OFF + 16), "n"(8 * OFF + 32), "n"(8 * OFF + 48)
+                 : "memory");
+  else
+    asm volatile("ds_read2_b64 %0, %4 offset0:%5 offset1:%6\n\tds_read2_b64 %1, %4 offset0:%7 offset1:%8\n\t"
+                 "ds_read2_b64 %2, %4 offset0:%9 offset1:%10\n\tds_read2_b64 %3, %4 offset0:%11 offset1:%12"
+                 : "=&v"(t.a), "=&v"(t.b), "=&v"(t.c), "=&v"(t.d)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 1), "n"(OFF + 2), "n"(OFF + 3), "n"(OFF + 4), "n"(OFF + 5), "n"(OFF + 6), "n"(OFF + 7)
+                 : "memory");
+}
+template <int LEFT>                   // wait until at most LEFT reads issued after t's are outstanding
+__device__ __forceinline__ void bcast8_wait(Bc8& t)
+{
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t.a), "+v"(t.b), "+v"(t.c), "+v"(t.d) : "n"(LEFT));
+}
+// v[8 H .. 8 H + 7] -= t * s
+template <int H>
+__device__ __forceinline__ void axpy8(d16& v, const Bc8& t, double s)
+{
+  v[8 * H + 0] = fma(-s, t.a.x, v[8 * H + 0]);
+  v[8 * H + 1] = fma(-s, t.a.y, v[8 * H + 1]);
+  v[8 * H + 2] = fma(-s, t.b.x, v[8 * H + 2]);
+  v[8 * H + 3] = fma(-s, t.b.y, v[8 * H + 3]);
+  v[8 * H + 4] = fma(-s, t.c.x, v[8 * H + 4]);
+  v[8 * H + 5] = fma(-s, t.c.y, v[8 * H + 5]);
+  v[8 * H + 6] = fma(-s, t.d.x, v[8 * H + 6]);
+  v[8 * H + 7] = fma(-s, t.d.y, v[8 * H + 7]);
+}
+// quarters QLO..QHI of the row -= m[16 QLO .. 16 QHI + 15] * s, m at LDS byte address addr (16-byte aligned if ALIGNED;
+// the multiplier is rounded as fma(-s, m, v) == fma(-m, s, v))
+template <int QLO, int QHI, bool ALIGNED>
+__device__ __forceinline__ void axpy_quarters(d16& q0, d16& q1, d16& q2, d16& q3, unsigned addr, double s)
+{
+  constexpr int nc = 2 * (QHI - QLO + 1);          // chunks of eight
+  Bc8 t[nc];
+  bcast8_issue<ALIGNED, 16 * QLO>(t[0], addr);
+  if constexpr (nc > 1) bcast8_issue<ALIGNED, 16 * QLO + 8>(t[1], addr);
+  if constexpr (nc > 2) bcast8_issue<ALIGNED, 16 * QLO + 16>(t[2], addr);
+#define BL_CHUNK(C)                                                                                          \
+  if constexpr ((C) < nc) {                                                                                  \
+    bcast8_wait<(nc - 1 - (C) >= 2 ? 8 : 4 * (nc - 1 - (C)))>(t[(C)]);                                        \
+    if constexpr ((C) + 3 < nc) bcast8_issue<ALIGNED, 16 * QLO + 8 * ((C) + 3)>(t[(C) + 3 < nc ? (C) + 3 : 0], addr); \
+    constexpr int q = QLO + (C) / 2;                                                                         \
+    axpy8<(C) % 2>(quarter_of<(q < 4 ? q : 3)>(q0, q1, q2, q3), t[(C)], s);                                   \
   }
-  for (int k = 0; k < P; ++k) {
-    // the pivot row to LDS: the columns from k on, in pairs, by groups of 8 (a group wholly left of k is finished: zeros
-    // in the update below)
-    if (lane == k) {
-#pragma unroll
-      for (int g8 = 0; g8 < 8; ++g8)
-        if (8 * g8 + 7 >= k && 8 * g8 < P) {
-#pragma unroll
-          for (int jj = 0; jj < 8; jj += 2)
-            *reinterpret_cast<double2*>(buf + 8 * g8 + jj) = make_double2(r[8 * g8 + jj], r[8 * g8 + jj + 1]);
-        }
-    }
-    WAVE_SYNC();
-    const double akk = buf[k];
+  BL_CHUNK(0) BL_CHUNK(1) BL_CHUNK(2) BL_CHUNK(3) BL_CHUNK(4) BL_CHUNK(5) BL_CHUNK(6) BL_CHUNK(7)
+#undef BL_CHUNK
+}
+__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(size_t)p; }   // the LDS offset of a shared pointer
+
+// Cholesky on one wavefront: lane i keeps row i of the LOWER triangle (a_ij, j <= i) in registers.  At pivot k lane i's own
+// a_ik is the element it divides (u_i = a_ik / d: column k of the lower triangle is row k of the upper one), the u of all
+// rows go to LDS once and come back as broadcasts, and the update is a_ij -= u_i u_j over the quarters from k's on.  Same
+// arithmetic as round 2's w_chol_reg element for element (the same quotient, the same products subtracted in ascending k
+// by the same fused multiply-add): the factor is bit-identical (round 2: 65 us at P = 64 with three LDS round trips a pivot;
+// its LDS-resident predecessors 130; this one 26).  LOWER = false: M = U'U, reads the upper triangle, writes
+// U into it; LOWER = true: M = L L', reads the lower triangle, writes L and zeroes the strict upper triangle.
+// MIRROR (with LOWER = false): U' is written into the lower triangle as well, so that a ROW of U is contiguous too
+// (w_inverse_rl).  buf: 64 doubles of LDS, 16-byte aligned.
+template <bool LOWER, bool MIRROR, int Q>
+__device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, double* M, int P, int ld, int lane, double* buf)
+{
+  const int k_end = P < 16 * Q + 16 ? P : 16 * Q + 16;
+#pragma nounroll
+  for (int k = 16 * Q; k < k_end; ++k) {
+    const double c = quarter_of<Q>(r0, r1, r2, r3)[k & 15];
+    const double akk = bcast_f64(c, k);
     if (!(akk > 0.0)) return false;
     const double d = sqrt(akk);
-    const double a_kl = buf[lane];
-    WAVE_SYNC();
     double u = 0.0;
-    if (lane > k && lane < P) u = a_kl / d;
+    if (lane > k && lane < P) u = c / d;
+    buf[lane] = u;                                   // u_j = 0 for j <= k and outside the matrix: those columns do not move
     if (lane >= k && lane < P) {
       const double v = lane == k ? d : u;
-      if (LOWER) L_(M, lane, k) = v;
-      else L_(M, k, lane) = v;
+      if (LOWER || MIRROR) L_(M, lane, k) = v;
+      if (!LOWER) L_(M, k, lane) = v;
     }
-    buf[lane] = u;                                 // u_kj for j > k, 0 for j <= k and outside the matrix
     WAVE_SYNC();
-    // (rows i <= k have u = 0: unchanged; so are the columns j <= k, where u_kj = 0: their groups are skipped)
-#pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8)
-      if (8 * g8 + 7 > k && 8 * g8 < P) {
-#pragma unroll
-        for (int jj = 0; jj < 8; jj += 2) {
-          const double2 b2 = *reinterpret_cast<const double2*>(buf + 8 * g8 + jj);
-          r[8 * g8 + jj] = fma(-u, b2.x, r[8 * g8 + jj]);
-          r[8 * g8 + jj + 1] = fma(-u, b2.y, r[8 * g8 + jj + 1]);
-        }
-      }
+    axpy_quarters<Q, 3, true>(r0, r1, r2, r3, lds_addr(buf), u);
     WAVE_SYNC();
   }
+  return true;
+}
+template <bool LOWER, bool MIRROR = false>
+__device__ __forceinline__ bool w_chol_rl(double* M, int P, int ld, int lane, double* buf)
+{
+  d16 r0, r1, r2, r3;
+  auto load = [&](int j) {
+    const bool in = lane < P && j <= lane;
+    return in ? (LOWER ? L_(M, lane, j) : L_(M, j, lane)) : 0.0;
+  };
+  BL_FILL_ROW(r0, r1, r2, r3, load);
+  if (!chol_phase<LOWER, MIRROR, 0>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
+  if (!chol_phase<LOWER, MIRROR, 1>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
+  if (!chol_phase<LOWER, MIRROR, 2>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
+  if (!chol_phase<LOWER, MIRROR, 3>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
   if (LOWER) {
     for (int j = 1; j < P; ++j)
       if (lane < j && lane < P) L_(M, lane, j) = 0.0;
@@ -744,51 +751,54 @@ __device__ bool w_chol_reg(double* M, int P, int ld, int lane, double* buf)
   return true;
 }
 
-// S <- PP^{-1} given U (PP = U'U): S starts as I; lane c solves U'y = e_c then U x = y on its own
-// column of S (dot-product form, ascending k as the reference's trsm), four products in flight.
-__device__ void w_inverse_from_U(const double* U, double* S, int P, int ld, int lane)
+// S <- PP^{-1} given U and its mirror (PP = U'U): lane c solves U'y = e_c, then U x = y, on column c of S held in registers,
+// both solves in the column-oriented form of the reference BLAS (DTRSM, left, upper: once an entry is solved its multiple is
+// taken off every entry still open -- independent fused multiply-adds, where the dot-product form is one dependent chain per
+// lane and an LDS round trip per eight terms).  Per element that is the order of round 2's routine in the forward solve
+// (ascending) and the reverse of it in the backward solve (descending, as DTRSM has it).  Column i of the mirrored factor
+// holds what both need: U_mi above the diagonal (backward), U_im below it (forward).  Entries already solved are parked in S
+// and their registers are dead (a phase runs over whole quarters: whatever it leaves in a dead entry is never read).
+template <int Q>
+__device__ __forceinline__ void inverse_fwd_phase(d16& y0, d16& y1, d16& y2, d16& y3, const double* U, double* col, int P, int ld, int lane)
+{
+  const int i_end = P < 16 * Q + 16 ? P : 16 * Q + 16;
+#pragma nounroll
+  for (int i = 16 * Q; i < i_end; ++i) {
+    const double* ui = U + i * ld;
+    const double v = quarter_of<Q>(y0, y1, y2, y3)[i & 15] / ui[i];
+    if (lane < P) col[i] = v;
+    axpy_quarters<Q, 3, false>(y0, y1, y2, y3, lds_addr(ui), v);
+  }
+}
+template <int Q>
+__device__ __forceinline__ void inverse_bwd_phase(d16& y0, d16& y1, d16& y2, d16& y3, const double* U, double* col, int P, int ld, int lane)
+{
+#pragma nounroll
+  for (int i = (P < 16 * Q + 16 ? P : 16 * Q + 16) - 1; i >= 16 * Q; --i) {
+    const double* ui = U + i * ld;
+    const double v = quarter_of<Q>(y0, y1, y2, y3)[i & 15] / ui[i];
+    if (lane < P) col[i] = v;
+    axpy_quarters<0, Q, false>(y0, y1, y2, y3, lds_addr(ui), v);
+  }
+}
+__device__ __forceinline__ void w_inverse_rl(const double* U, double* S, int P, int ld, int lane)
 {
   const int c = lane < P ? lane : 0;
   double* col = S + c * ld;
-  for (int i = 0; i < P; ++i) {                            // forward: U' y = e_c
-    const double* ui = U + i * ld;                         // column i of U: U[k][i], k < i
-    double acc = col[i];
-    int k = 0;
-    // sixteen products in flight (one LDS round trip per sixteen: with four the loop was latency-bound), subtracted in order
-    for (; k + 15 < i; k += 16) {
-      double pr[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) pr[q] = ui[k + q] * col[k + q];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc = acc - pr[q];
-    }
-    for (; k + 3 < i; k += 4) {
-      const double p0 = ui[k] * col[k], p1 = ui[k + 1] * col[k + 1], p2 = ui[k + 2] * col[k + 2], p3 = ui[k + 3] * col[k + 3];
-      acc = (((acc - p0) - p1) - p2) - p3;
-    }
-    for (; k < i; ++k) acc -= ui[k] * col[k];
-    const double y = acc / ui[i];
-    if (lane < P) col[i] = y;
-  }
-  for (int i = P - 1; i >= 0; --i) {                       // backward: U x = y
-    double acc = col[i];
-    int k = i + 1;
-    for (; k + 15 < P; k += 16) {
-      double pr[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) pr[q] = L_(U, i, k + q) * col[k + q];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc = acc - pr[q];
-    }
-    for (; k + 3 < P; k += 4) {
-      const double p0 = L_(U, i, k) * col[k], p1 = L_(U, i, k + 1) * col[k + 1], p2 = L_(U, i, k + 2) * col[k + 2],
-                   p3 = L_(U, i, k + 3) * col[k + 3];
-      acc = (((acc - p0) - p1) - p2) - p3;
-    }
-    for (; k < P; ++k) acc -= L_(U, i, k) * col[k];
-    const double x = acc / L_(U, i, i);
-    if (lane < P) col[i] = x;
-  }
+  d16 y0, y1, y2, y3;
+  auto unit = [&](int j) { return j == lane ? 1.0 : 0.0; };
+  BL_FILL_ROW(y0, y1, y2, y3, unit);
+  inverse_fwd_phase<0>(y0, y1, y2, y3, U, col, P, ld, lane);                  // forward: U' y = e_c
+  inverse_fwd_phase<1>(y0, y1, y2, y3, U, col, P, ld, lane);
+  inverse_fwd_phase<2>(y0, y1, y2, y3, U, col, P, ld, lane);
+  inverse_fwd_phase<3>(y0, y1, y2, y3, U, col, P, ld, lane);
+  WAVE_SYNC();
+  auto parked = [&](int j) { return j < P ? col[j] : 0.0; };
+  BL_FILL_ROW(y0, y1, y2, y3, parked);
+  inverse_bwd_phase<3>(y0, y1, y2, y3, U, col, P, ld, lane);                  // backward: U x = y
+  inverse_bwd_phase<2>(y0, y1, y2, y3, U, col, P, ld, lane);
+  inverse_bwd_phase<1>(y0, y1, y2, y3, U, col, P, ld, lane);
+  inverse_bwd_phase<0>(y0, y1, y2, y3, U, col, P, ld, lane);
   WAVE_SYNC();
 }
 
@@ -827,6 +837,31 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
 __device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lane, int cvec, double svec, double z1v,
                                          const double* Rk, double* zw, double* zk, double* zz, double& bj);
 
+// The tnorm records of a constrained draw at P <= 64: record e = (scan k, move i) from its nine uniforms (per scan k, P-1
+// r.flat for the shuffle, then P tnorm calls of 9 uniforms; a call owns its nine whatever its bounds), one thread a record.
+// They depend on (seed, epoch, P) alone.
+__global__ __launch_bounds__(256) void k_beta64_records(blk::BetaArgs a)
+{
+  if (*a.dead != 0) return;
+  const int P = a.P, e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= P * P) return;
+  const uint32_t per_scan = (uint32_t)(10 * P - 1);
+  const int k = e / P, i = e % P;
+  const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
+  double* R = a.work + (size_t)e * kRec;
+  for (int m = 0; m < 4; ++m) {
+    const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
+    const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
+    const double lua = log(ua);
+    R[4 * m] = ua;
+    R[4 * m + 1] = lua;
+    R[4 * m + 2] = log(ub);
+    R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
+  }
+  R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
+  R[17] = R[18] = R[19] = 0.0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
 {
   extern __shared__ double lds[];
@@ -843,7 +878,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   int* ptab = perm + P + (P & 1);                    // ptab[k][i]: coordinate visited at step i of scan k (P*P ints)
   double* recL = reinterpret_cast<double*>(ptab + P * P + ((P * P) & 1));   // 2 x P records: the scan in progress / next
   double* rec = a.work;                             // P*P records of kRec doubles
-  __shared__ __attribute__((aligned(16))) double s_piv[64];   // w_chol_reg's pivot row
+  __shared__ __attribute__((aligned(16))) double s_piv[64];   // w_chol_rl's multipliers
   __shared__ int bad;
   __shared__ int uflag;                              // 0: U not ready; 1: U = chol(PP) is in A; 2: PP not positive definite
   if (t == 0) bad = 0;
@@ -855,6 +890,10 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
     if (need_inverse) L_(S, i, j) = (i == j) ? 1.0 : 0.0;
   }
+  if (t < P + 8) {                                   // the padding row of every column of PP, and the first entries of S when it is
+    if (t < P) L_(A, P, t) = 0.0;                    // not used: w_inverse_rl's groups of eight read them (times exact zeros)
+    if (!need_inverse && t >= P) S[t - P] = 0.0;
+  }
   __syncthreads();
 
   if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
@@ -862,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     // for the workgroup routines with their two or three barriers per pivot; same arithmetic, same bits)
     if (t < 64) {
       const int lane = t;
-      if (!w_chol_reg<false>(A, P, ld, lane, s_piv)) {
+      if (!w_chol_rl<false, true>(A, P, ld, lane, s_piv)) {
         if (lane == 0) (atomicOr(a.status, ST_NOT_PD), atomicOr(a.dead, 1));
       } else {
         double m = lane < P ? a.bP[lane] : 0.0;
@@ -888,13 +927,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   if (t < 64) {
     // ================= wave 0: the dense stage, alone, no workgroup barriers =================
     const int lane = t;
-    bool ok = w_chol_reg<false>(A, P, ld, lane, s_piv);                       // U = chol(PP,'U')
+    bool ok = w_chol_rl<false, true>(A, P, ld, lane, s_piv);                  // U = chol(PP,'U'), and U' below it
     // wave 1 solves for mP from U once its own work is done (it idles otherwise): hand U over
     __threadfence_block();
     if (lane == 0) __hip_atomic_store(&uflag, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
     if (ok && need_inverse) {
-      w_inverse_from_U(A, S, P, ld, lane);                                     // S = PP^{-1}
+      w_inverse_rl(A, S, P, ld, lane);                                         // S = PP^{-1}
       if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
       if (mode == blk::B_FROM_LIK) {
         // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps               (Normal.hpp:98-131)
@@ -906,7 +945,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           zz[lane] = e;
         }
         WAVE_SYNC();
-        ok = w_chol_lower(S, P, ld, lane);
+        ok = w_chol_rl<true>(S, P, ld, lane, s_piv);
         if (ok && lane < P) {
           double le = 0.0;
           for (int k2 = 0; k2 <= lane; ++k2) le += L_(S, lane, k2) * zz[k2];
@@ -915,36 +954,17 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
       } else {
         // B_CONSTRAINED set-up, Logit.hpp:335-366 (mP: wave 1; z: after the barrier, when mP is there)
         if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
-        ok = w_chol_reg<true>(S, P, ld, lane, s_piv);                         // L = chol(S,'L')
+        ok = w_chol_rl<true>(S, P, ld, lane, s_piv);                          // L = chol(S,'L')
         if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
       }
     }
     if (!ok && t == 0) bad = 1;
   } else if (mode == blk::B_CONSTRAINED) {
-    // ====== waves 1-3, meanwhile: every random input of the draw, in stream order
-    // (per scan k, P-1 r.flat for the shuffle, then P tnorm calls of 9 uniforms) ======
+    // ====== wave 1, meanwhile: the scan tables and mP.  (The tnorm records -- every other random input of the draw, in stream
+    // order: DESIGN.md section 2 -- come from k_beta64_records, launched in front of this kernel: three wavefronts took 118 us
+    // over them here, longer than the dense stage beside them takes since round 3.) ======
     const int tt = t - 64;
     const uint32_t per_scan = (uint32_t)(10 * P - 1);
-    // the tnorm records: waves 2-3 take the first 25/32 of them, wave 1 the rest once the scan tables are built
-    const int nsplit = (P * P * 25) / 32;
-    auto records = [&](int e0, int e1, int first, int stride) {
-      for (int e = e0 + first; e < e1; e += stride) {
-        const int k = e / P, i = e % P;
-        const uint32_t base = (uint32_t)k * per_scan + (uint32_t)(P - 1) + 9u * (uint32_t)i;
-        double* R = rec + (size_t)e * kRec;
-        for (int m = 0; m < 4; ++m) {
-          const double ua = beta_stream_unif(a.seed, a.epoch, base + 2 * m);
-          const double ub = beta_stream_unif(a.seed, a.epoch, base + 2 * m + 1);
-          const double lua = log(ua);
-          R[4 * m] = ua;
-          R[4 * m + 1] = lua;
-          R[4 * m + 2] = log(ub);
-          R[4 * m + 3] = sqrt(-2.0 * lua) * cospi(2.0 * ub);
-        }
-        R[16] = beta_stream_unif(a.seed, a.epoch, base + 8);
-        R[17] = R[18] = R[19] = 0.0;
-      }
-    };
     if (tt < 64) {
       // wave 1: the scan tables.  Scan k's P-1 swaps (r.flat(i, P), Logit.hpp:375-377) applied to the identity,
       // all scans in parallel (lane k, its row of ptab as scratch), then composed in scan order: `is` persists
@@ -969,7 +989,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         if (tt < P) ptab[k * P + tt] = v;
         WAVE_SYNC();
       }
-      records(nsplit, P * P, tt, 64);
       // mP = U^{-1} U^{-T} bP (Logit.hpp:335-340), as soon as wave 0 has published U (long since, normally)
       int f;
       do {
@@ -982,11 +1001,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         m = w_solve_U_vec(A, m, P, ld, tt);
         if (tt < P) mP[tt] = m;
       }
-    } else {
-      records(0, nsplit, tt - 64, kBlock - 128);
     }
-    // the records are read back (staged into LDS) by every wave after the barrier below
-    __threadfence_block();
     if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
   }
   if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
@@ -1997,6 +2012,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
                        2 * (size_t)a.P * kRec * 8 + 32;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_beta64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (mode == B_CONSTRAINED) hipLaunchKernelGGL(k_beta64_records, dim3((a.P * a.P + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
     return;
   }
