@@ -706,15 +706,21 @@ __device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned
 // U into it; LOWER = true: M = L L', reads the lower triangle, writes L and zeroes the strict upper triangle.
 // MIRROR (with LOWER = false): U' is written into the lower triangle as well, so that a ROW of U is contiguous too
 // (w_inverse_rl).  buf: 64 doubles of LDS, 16-byte aligned.
+// progress (optional, LDS): pivots finished, published behind each pivot's writes for a wave that follows this one
+// (w_inverse_rl's forward solve needs row k of U and no more at its step k); kCholFailed when a pivot is not positive.
+constexpr int kCholFailed = 1 << 20;
 template <bool LOWER, bool MIRROR, int Q>
-__device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, double* M, int P, int ld, int lane, double* buf)
+__device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, double* M, int P, int ld, int lane, double* buf, int* progress)
 {
   const int k_end = P < 16 * Q + 16 ? P : 16 * Q + 16;
 #pragma nounroll
   for (int k = 16 * Q; k < k_end; ++k) {
     const double c = quarter_of<Q>(r0, r1, r2, r3)[k & 15];
     const double akk = bcast_f64(c, k);
-    if (!(akk > 0.0)) return false;
+    if (!(akk > 0.0)) {
+      if (progress && lane == 0) __hip_atomic_store(progress, kCholFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return false;
+    }
     const double d = sqrt(akk);
     double u = 0.0;
     if (lane > k && lane < P) u = c / d;
@@ -725,13 +731,15 @@ __device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, d
       if (!LOWER) L_(M, k, lane) = v;
     }
     WAVE_SYNC();
+    // (LDS executes a wavefront's operations in order: the word lands behind the pivot's writes without a wait)
+    if (progress && lane == 0) __hip_atomic_store(progress, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     axpy_quarters<Q, 3, true>(r0, r1, r2, r3, lds_addr(buf), u);
     WAVE_SYNC();
   }
   return true;
 }
 template <bool LOWER, bool MIRROR = false>
-__device__ __forceinline__ bool w_chol_rl(double* M, int P, int ld, int lane, double* buf)
+__device__ __forceinline__ bool w_chol_rl(double* M, int P, int ld, int lane, double* buf, int* progress = nullptr)
 {
   d16 r0, r1, r2, r3;
   auto load = [&](int j) {
@@ -739,10 +747,10 @@ __device__ __forceinline__ bool w_chol_rl(double* M, int P, int ld, int lane, do
     return in ? (LOWER ? L_(M, lane, j) : L_(M, j, lane)) : 0.0;
   };
   BL_FILL_ROW(r0, r1, r2, r3, load);
-  if (!chol_phase<LOWER, MIRROR, 0>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
-  if (!chol_phase<LOWER, MIRROR, 1>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
-  if (!chol_phase<LOWER, MIRROR, 2>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
-  if (!chol_phase<LOWER, MIRROR, 3>(r0, r1, r2, r3, M, P, ld, lane, buf)) return false;
+  if (!chol_phase<LOWER, MIRROR, 0>(r0, r1, r2, r3, M, P, ld, lane, buf, progress)) return false;
+  if (!chol_phase<LOWER, MIRROR, 1>(r0, r1, r2, r3, M, P, ld, lane, buf, progress)) return false;
+  if (!chol_phase<LOWER, MIRROR, 2>(r0, r1, r2, r3, M, P, ld, lane, buf, progress)) return false;
+  if (!chol_phase<LOWER, MIRROR, 3>(r0, r1, r2, r3, M, P, ld, lane, buf, progress)) return false;
   if (LOWER) {
     for (int j = 1; j < P; ++j)
       if (lane < j && lane < P) L_(M, lane, j) = 0.0;
@@ -759,16 +767,24 @@ __device__ __forceinline__ bool w_chol_rl(double* M, int P, int ld, int lane, do
 // holds what both need: U_mi above the diagonal (backward), U_im below it (forward).  Entries already solved are parked in S
 // and their registers are dead (a phase runs over whole quarters: whatever it leaves in a dead entry is never read).
 template <int Q>
-__device__ __forceinline__ void inverse_fwd_phase(d16& y0, d16& y1, d16& y2, d16& y3, const double* U, double* col, int P, int ld, int lane)
+__device__ __forceinline__ bool inverse_fwd_phase(d16& y0, d16& y1, d16& y2, d16& y3, const double* U, double* col, int P, int ld, int lane,
+                                                  const int* progress)
 {
   const int i_end = P < 16 * Q + 16 ? P : 16 * Q + 16;
 #pragma nounroll
   for (int i = 16 * Q; i < i_end; ++i) {
+    if (progress) {                       // the factorisation runs on another wavefront: step i needs its pivots 0 .. i
+      int done;
+      while ((done = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= i) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (done >= kCholFailed) return false;
+    }
     const double* ui = U + i * ld;
     const double v = quarter_of<Q>(y0, y1, y2, y3)[i & 15] / ui[i];
     if (lane < P) col[i] = v;
     axpy_quarters<Q, 3, false>(y0, y1, y2, y3, lds_addr(ui), v);
   }
+  return true;
 }
 template <int Q>
 __device__ __forceinline__ void inverse_bwd_phase(d16& y0, d16& y1, d16& y2, d16& y3, const double* U, double* col, int P, int ld, int lane)
@@ -781,17 +797,19 @@ __device__ __forceinline__ void inverse_bwd_phase(d16& y0, d16& y1, d16& y2, d16
     axpy_quarters<0, Q, false>(y0, y1, y2, y3, lds_addr(ui), v);
   }
 }
-__device__ __forceinline__ void w_inverse_rl(const double* U, double* S, int P, int ld, int lane)
+// progress (optional): see chol_phase -- the forward solve then runs a step behind the factorisation of another wavefront and
+// costs no time of its own; false: that factorisation failed.
+__device__ __forceinline__ bool w_inverse_rl(const double* U, double* S, int P, int ld, int lane, const int* progress = nullptr)
 {
   const int c = lane < P ? lane : 0;
   double* col = S + c * ld;
   d16 y0, y1, y2, y3;
   auto unit = [&](int j) { return j == lane ? 1.0 : 0.0; };
   BL_FILL_ROW(y0, y1, y2, y3, unit);
-  inverse_fwd_phase<0>(y0, y1, y2, y3, U, col, P, ld, lane);                  // forward: U' y = e_c
-  inverse_fwd_phase<1>(y0, y1, y2, y3, U, col, P, ld, lane);
-  inverse_fwd_phase<2>(y0, y1, y2, y3, U, col, P, ld, lane);
-  inverse_fwd_phase<3>(y0, y1, y2, y3, U, col, P, ld, lane);
+  if (!inverse_fwd_phase<0>(y0, y1, y2, y3, U, col, P, ld, lane, progress)) return false;     // forward: U' y = e_c
+  if (!inverse_fwd_phase<1>(y0, y1, y2, y3, U, col, P, ld, lane, progress)) return false;
+  if (!inverse_fwd_phase<2>(y0, y1, y2, y3, U, col, P, ld, lane, progress)) return false;
+  if (!inverse_fwd_phase<3>(y0, y1, y2, y3, U, col, P, ld, lane, progress)) return false;
   WAVE_SYNC();
   auto parked = [&](int j) { return j < P ? col[j] : 0.0; };
   BL_FILL_ROW(y0, y1, y2, y3, parked);
@@ -800,6 +818,7 @@ __device__ __forceinline__ void w_inverse_rl(const double* U, double* S, int P, 
   inverse_bwd_phase<1>(y0, y1, y2, y3, U, col, P, ld, lane);
   inverse_bwd_phase<0>(y0, y1, y2, y3, U, col, P, ld, lane);
   WAVE_SYNC();
+  return true;
 }
 
 // b <- U'^{-1} b, b_j in lane j's register
@@ -880,20 +899,16 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double* rec = a.work;                             // P*P records of kRec doubles
   __shared__ __attribute__((aligned(16))) double s_piv[64];   // w_chol_rl's multipliers
   __shared__ int bad;
-  __shared__ int uflag;                              // 0: U not ready; 1: U = chol(PP) is in A; 2: PP not positive definite
+  __shared__ int progress;                           // wavefront 0's pivots done (kCholFailed: not positive definite)
+  __shared__ __attribute__((aligned(16))) double s_piv2[64];  // the multipliers of wavefront 2's Cholesky
   if (t == 0) bad = 0;
-  if (t == 0) uflag = 0;
+  if (t == 0) progress = 0;
   if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
-  const bool need_inverse = mode == blk::B_CONSTRAINED || mode == blk::B_FROM_LIK;
   for (int e = t; e < P * P; e += kBlock) {
     const int i = e % P, j = e / P;
     L_(A, i, j) = a.PPsum[e] + a.P0[e];              // PP = P0 + X'OmX
-    if (need_inverse) L_(S, i, j) = (i == j) ? 1.0 : 0.0;
   }
-  if (t < P + 8) {                                   // the padding row of every column of PP, and the first entries of S when it is
-    if (t < P) L_(A, P, t) = 0.0;                    // not used: w_inverse_rl's groups of eight read them (times exact zeros)
-    if (!need_inverse && t >= P) S[t - P] = 0.0;
-  }
+  if (t < P) L_(A, P, t) = 0.0;                      // the padding row of every column (read into dead entries only)
   __syncthreads();
 
   if (mode == blk::B_SOLVE || mode == blk::B_MVN) {
@@ -924,17 +939,28 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
     return;
   }
 
+  // ================= the dense stage, no workgroup barriers =================
+  // wavefront 0: U = chol(PP,'U'), one pivot after the other, each published; then mP (constrained draw)
+  // wavefront 2: S = PP^{-1} -- the forward solve a step behind wavefront 0's pivots (its step i needs row i of U), the
+  //              backward solve when U is whole -- and L = chol(S,'L')
+  // wavefront 1: the scan tables (constrained draw)
   if (t < 64) {
-    // ================= wave 0: the dense stage, alone, no workgroup barriers =================
     const int lane = t;
-    bool ok = w_chol_rl<false, true>(A, P, ld, lane, s_piv);                  // U = chol(PP,'U'), and U' below it
-    // wave 1 solves for mP from U once its own work is done (it idles otherwise): hand U over
-    __threadfence_block();
-    if (lane == 0) __hip_atomic_store(&uflag, ok ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool ok = w_chol_rl<false, true>(A, P, ld, lane, s_piv, &progress);  // U = chol(PP,'U'), and U' below it
     if (a.dbg && t == 0) a.dbg[3] = wall_clock64();
-    if (ok && need_inverse) {
-      w_inverse_rl(A, S, P, ld, lane);                                         // S = PP^{-1}
-      if (a.dbg && t == 0) a.dbg[4] = wall_clock64();
+    if (!ok && t == 0) bad = 1;
+    if (ok && mode == blk::B_CONSTRAINED) {
+      // mP = U^{-1} U^{-T} bP (Logit.hpp:335-340)
+      double m = lane < P ? a.bP[lane] : 0.0;
+      m = w_solve_Ut_vec(A, m, P, ld, lane);
+      m = w_solve_U_vec(A, m, P, ld, lane);
+      if (lane < P) mP[lane] = m;
+    }
+  } else if (t >= 128 && t < 192) {
+    const int lane = t - 128;
+    bool ok = w_inverse_rl(A, S, P, ld, lane, &progress);                      // S = PP^{-1}
+    if (a.dbg && lane == 0) a.dbg[4] = wall_clock64();
+    if (ok) {
       if (mode == blk::B_FROM_LIK) {
         // mean = V b ; lower = chol(V,'L') ; beta = mean + lower eps               (Normal.hpp:98-131)
         double mean = 0.0, e = 0.0;
@@ -945,62 +971,47 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
           zz[lane] = e;
         }
         WAVE_SYNC();
-        ok = w_chol_rl<true>(S, P, ld, lane, s_piv);
+        ok = w_chol_rl<true>(S, P, ld, lane, s_piv2);
         if (ok && lane < P) {
           double le = 0.0;
           for (int k2 = 0; k2 <= lane; ++k2) le += L_(S, lane, k2) * zz[k2];
           a.beta_out[lane] = le + mean;
         }
       } else {
-        // B_CONSTRAINED set-up, Logit.hpp:335-366 (mP: wave 1; z: after the barrier, when mP is there)
-        if (a.dbg && t == 0) a.dbg[1] = wall_clock64();
-        ok = w_chol_rl<true>(S, P, ld, lane, s_piv);                          // L = chol(S,'L')
-        if (a.dbg && t == 0) a.dbg[2] = wall_clock64();
+        // B_CONSTRAINED set-up, Logit.hpp:335-366 (z: after the barrier, when mP is there)
+        if (a.dbg && lane == 0) a.dbg[1] = wall_clock64();
+        ok = w_chol_rl<true>(S, P, ld, lane, s_piv2);                         // L = chol(S,'L')
+        if (a.dbg && lane == 0) a.dbg[2] = wall_clock64();
       }
+      if (!ok && lane == 0) bad = 1;
     }
-    if (!ok && t == 0) bad = 1;
-  } else if (mode == blk::B_CONSTRAINED) {
-    // ====== wave 1, meanwhile: the scan tables and mP.  (The tnorm records -- every other random input of the draw, in stream
+  } else if (mode == blk::B_CONSTRAINED && t >= 64 && t < 128) {
+    // ====== wave 1, meanwhile: the scan tables.  (The tnorm records -- every other random input of the draw, in stream
     // order: DESIGN.md section 2 -- come from k_beta64_records, launched in front of this kernel: three wavefronts took 118 us
     // over them here, longer than the dense stage beside them takes since round 3.) ======
     const int tt = t - 64;
     const uint32_t per_scan = (uint32_t)(10 * P - 1);
-    if (tt < 64) {
-      // wave 1: the scan tables.  Scan k's P-1 swaps (r.flat(i, P), Logit.hpp:375-377) applied to the identity,
-      // all scans in parallel (lane k, its row of ptab as scratch), then composed in scan order: `is` persists
-      // across scans (Logit.hpp:368-377); the composition is in place, row by row.  One wavefront: no
-      // workgroup barrier, wave 0 is in the dense stage.
-      if (tt < P) {
-        int* sg = ptab + tt * P;
-        for (int i = 0; i < P; ++i) sg[i] = i;
-        for (int i = 0; i < P - 1; ++i) {
-          const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)tt * per_scan + (uint32_t)i);
-          const int j = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P)
-          const int tmp = sg[i];
-          sg[i] = sg[j];
-          sg[j] = tmp;
-        }
+    // Scan k's P-1 swaps (r.flat(i, P), Logit.hpp:375-377) applied to the identity, all scans in parallel (lane k, its row
+    // of ptab as scratch), then composed in scan order: `is` persists across scans (Logit.hpp:368-377); the composition is in
+    // place, row by row.  One wavefront: no workgroup barrier.
+    if (tt < P) {
+      int* sg = ptab + tt * P;
+      for (int i = 0; i < P; ++i) sg[i] = i;
+      for (int i = 0; i < P - 1; ++i) {
+        const double u = beta_stream_unif(a.seed, a.epoch, (uint32_t)tt * per_scan + (uint32_t)i);
+        const int j = (int)(unsigned)((double)i + ((double)P - (double)i) * u);     // r.flat(i, P)
+        const int tmp = sg[i];
+        sg[i] = sg[j];
+        sg[j] = tmp;
       }
+    }
+    WAVE_SYNC();
+    for (int k = 1; k < P; ++k) {
+      int v = 0;
+      if (tt < P) v = ptab[(k - 1) * P + ptab[k * P + tt]];
       WAVE_SYNC();
-      for (int k = 1; k < P; ++k) {
-        int v = 0;
-        if (tt < P) v = ptab[(k - 1) * P + ptab[k * P + tt]];
-        WAVE_SYNC();
-        if (tt < P) ptab[k * P + tt] = v;
-        WAVE_SYNC();
-      }
-      // mP = U^{-1} U^{-T} bP (Logit.hpp:335-340), as soon as wave 0 has published U (long since, normally)
-      int f;
-      do {
-        f = __hip_atomic_load(&uflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!f) __builtin_amdgcn_s_sleep(8);
-      } while (!f);
-      if (f == 1) {
-        double m = tt < P ? a.bP[tt] : 0.0;
-        m = w_solve_Ut_vec(A, m, P, ld, tt);
-        m = w_solve_U_vec(A, m, P, ld, tt);
-        if (tt < P) mP[tt] = m;
-      }
+      if (tt < P) ptab[k * P + tt] = v;
+      WAVE_SYNC();
     }
     if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
   }
