@@ -852,6 +852,14 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
   return b;
 }
 
+// the cheap pass of a scan of P = 64 moves on the four wavefronts, 16 moves each (defined with k_beta_sweeps_run's pieces, below)
+template <int HB0, int HB1>
+__device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane, int cvec, double svec, double z1v, double* zw,
+                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8]);
+// ... and what is left of such a scan when some move needs its bounds, on the wavefront that walked the whole chain
+__device__ __forceinline__ int quad_slow(const double (&cur)[64], const double (&cp)[8], double bs_end, uint32_t Fb0, int lane,
+                                         int cvec, double svec, double z1v, const double* Rk, double* zw, double* zk, double* zz,
+                                         double& bj);
 // one scan of the constrained sweeps on one wavefront (defined with k_beta_sweeps_run's pieces, below)
 __device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lane, int cvec, double svec, double z1v,
                                          const double* Rk, double* zw, double* zk, double* zz, double& bj);
@@ -881,7 +889,7 @@ __global__ __launch_bounds__(256) void k_beta64_records(blk::BetaArgs a)
   R[17] = R[18] = R[19] = 0.0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
+__global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, int quad_ok)
 {
   extern __shared__ double lds[];
   // a Cholesky factorisation failed earlier in this chain (the chain's own flag, BetaArgs::dead: another handle's failure does not stop this one):
@@ -1068,35 +1076,70 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
   double bj = row ? a.beta_prev[lane] : 0.0;       // beta_j, replicated in every wavefront
   const double inf = __builtin_huge_val();
   const int nrec = P * kRec;
-  __shared__ __attribute__((aligned(16))) double s_zw[128], s_zk[64], s_bj[2][64];  // solo_scan's hand-over slots; beta and the count it leaves for the other waves
+  __shared__ __attribute__((aligned(16))) double s_zw[4][128], s_zk[64], s_bj[2][64];  // the scans' hand-over slots; beta and the count left for the other waves
   __shared__ int s_nf[2];                                                            // (by scan parity: one barrier per scan)
-  for (int e = t; e < nrec; e += kBlock) recL[e] = rec[e];
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) uint32_t s_fb[2][4];                       // quad_pass: the four verdicts, by scan parity
+  // the cheap pass on the four wavefronts (a full matrix: every lane a row and a move); bl_diag_beta_sweeps(0): on one, as for P < 64
+  const bool quad = P == 64 && quad_ok != 0;
+  // The records stay in global memory (L2: k_beta64_records wrote them just now) while the scans speculate -- a scan then needs
+  // one number of each, the first normal, fetched a scan ahead; a move redone with its bounds reads its record from there
+  // (4 moves in 4096 on C4).  A chain pressed against its bounds reads four numbers a move: its scans stage their records
+  // into LDS first.
   bool spec_on = true;
+  double svec_n = row ? rec[lane * kRec + 3] : 0.0;                 // lane i: attempt 0's normal of move i of scan 0
   for (int k = 0; k < P; ++k) {
-    const double* Rk = recL + (k & 1) * nrec;
-    // next scan's records: global -> registers now, -> LDS at the end of this scan
-    constexpr int kStage = (64 * kRec + kBlock - 1) / kBlock;      // P <= 64
-    double stage[kStage];
-    if (k + 1 < P) {
-      const double* src = rec + (size_t)(k + 1) * nrec;
-#pragma unroll
-      for (int q = 0; q < kStage; ++q) {
-        const int e = t + q * kBlock;
-        stage[q] = e < nrec ? src[e] : 0.0;
-      }
+    const double* Rk = rec + (size_t)k * nrec;
+    const double svec = svec_n;
+    if (k + 1 < P) svec_n = row ? rec[(size_t)(k + 1) * nrec + lane * kRec + 3] : 0.0;
+    if (!spec_on) {
+      for (int e = t; e < nrec; e += kBlock) recL[e] = Rk[e];
+      __syncthreads();
+      Rk = recL;
     }
     const int g4 = (lane < 5 ? lane : 0) * 4;
     const double qnan = __builtin_nan("");
     const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
-    const double svec = row ? Rk[lane * kRec + 3] : 0.0;         // lane i: attempt 0's normal of move i
     const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
     int nfail = 0;                                                 // moves taken with their exact bounds in this scan
+    if (spec_on && quad) {
+      // the scan's cheap pass on the four wavefronts, 16 moves each; if every move takes its first normal (15 scans in 16
+      // on C4) that was the scan
+      double bs, cur[64], cp[8];
+      uint32_t vb;
+      switch (wave) {
+        // (a wave pays 36 cycles for a move it only walks -- its column of L, its term of the chain -- and 77 for one it
+        // tests: 32 / 16 / 8 / 8 moves even the four out)
+        case 0: vb = quad_pass<0, 4>(S, ld, lane, cvec, svec, z1v, s_zw[0], bj, bs, cur, cp); break;
+        case 1: vb = quad_pass<4, 6>(S, ld, lane, cvec, svec, z1v, s_zw[1], bj, bs, cur, cp); break;
+        case 2: vb = quad_pass<6, 7>(S, ld, lane, cvec, svec, z1v, s_zw[2], bj, bs, cur, cp); break;
+        default: vb = quad_pass<7, 8>(S, ld, lane, cvec, svec, z1v, s_zw[3], bj, bs, cur, cp); break;
+      }
+      if (lane == 0) s_fb[k & 1][wave] = vb;
+      if (wave == 3) s_bj[k & 1][lane] = bs;
+      __syncthreads();
+      const uint4 fb = *reinterpret_cast<const uint4*>(s_fb[k & 1]);
+      const uint32_t Fb = __builtin_amdgcn_readfirstlane((int)(fb.x | fb.y | fb.z | fb.w));
+      if (Fb == 0u) {
+        // The one barrier of such a scan.  Every wavefront writes the scan's z (the same values to the same words: each reads
+        // its own later), the slots go by the scan's parity, and nobody can be two scans ahead of anybody.
+        bj = s_bj[k & 1][lane];
+        zz[cvec] = svec;
+        continue;
+      }
+      // some move needs its bounds: the wavefront that holds the whole scan finishes it (solo_scan's second part), the others wait
+      if (wave == 3) {
+        const long long tq0 = a.dbg ? clock64() : 0;
+        nfail = quad_slow(cur, cp, bs, Fb, lane, cvec, svec, z1v, Rk, s_zw[3], s_zk, zz, bj);
+        if (a.dbg && lane == 0) a.dbg[14] += (unsigned long long)(clock64() - tq0);
+        s_bj[k & 1][lane] = bj;
+        if (lane == 0) s_nf[k & 1] = nfail;
+      }
+    } else
     if (spec_on) {
       // the scan as one speculative segment on wavefront 0 (the others stage the next records and wait)
       if (wave == 0) {
         const long long tq0 = a.dbg ? clock64() : 0;
-        nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw, s_zk, zz, bj);
+        nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw[0], s_zk, zz, bj);
         if (a.dbg && t == 0) a.dbg[14] += (unsigned long long)(clock64() - tq0);
         s_bj[k & 1][lane] = bj;
         if (lane == 0) s_nf[k & 1] = nfail;
@@ -1131,20 +1174,12 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode)
         if (wave == 0 && lane == 0) zz[c] = z2;
       }
     }
-    if (k + 1 < P) {
-      double* Rn = recL + ((k + 1) & 1) * nrec;
-#pragma unroll
-      for (int q = 0; q < kStage; ++q) {
-        const int e = t + q * kBlock;
-        if (e < nrec) Rn[e] = stage[q];
-      }
-    }
     __syncthreads();
     const bool was_solo = spec_on;
     if (was_solo) nfail = s_nf[k & 1];   // wavefront 0's scan: its count to every wavefront
     // a chain pressed against its bounds gains nothing from speculating: move by move then, look again every 8th scan
     spec_on = 2 * nfail < P || ((k + 1) & 7) == 0;
-    if (was_solo && !spec_on && wave != 0) bj = s_bj[k & 1][lane];   // the replicas are needed again: wavefront 0's beta
+    if (was_solo && (quad || !spec_on)) bj = s_bj[k & 1][lane];   // the replicas are needed again: the beta of the wavefront that made the scan
     if (a.dbg && t == 0) a.dbg[8] += (unsigned long long)nfail;
   }
   if (wave == 0 && row) a.beta_out[lane] = bj;
@@ -1781,6 +1816,55 @@ __global__ __launch_bounds__(1024) void k_beta_scan_tables(blk::BetaArgs a)
   }                                                                                                                         \
   }
 
+// The cheap pass of a scan at P = 64 on FOUR wavefronts.  With every move of the scan taking its first normal, dz is known
+// for the whole scan up front, so the chain value before move u is beta_j plus the first u terms of one sum: a wavefront walks
+// the chain alone through the moves of the wavefronts before it (one FMA a move, in the one-wavefront order: the same bits)
+// and tests its own moves -- solo_scan's pass, element for element.  Returns the wave's verdict (bit h: half-block h
+// failed somewhere in the matrix) and in bs_out the chain value behind its last move (the last wavefront's is the scan's end).
+// zw: the wave's own 128-double slot.
+template <int H>
+__device__ __forceinline__ void run_chain(const double (&l1)[64], const double (&dz)[8], double& bs)
+{
+#pragma unroll
+  for (int u = 0; u < 8; ++u) bs = fma(l1[8 * H + u], dz[u], bs);
+}
+template <int HB0, int HB1>      // the wave tests half-blocks HB0 .. HB1 - 1 (of eight moves each) and walks the chain up to them
+__device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane, int cvec, double svec, double z1v, double* zw,
+                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8])
+{
+  const bool lastrow = lane == 63;                           // row P-1 is not constrained (Logit.hpp:383: j < P-1)
+  *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(svec - z1v, z1v);
+  const int co = cvec * ld;                                  // cur: L(lane, c_u) for the moves u < 8 HB1
+#pragma unroll
+  for (int u = 0; u < 64; ++u) cur[u] = u < 8 * HB1 ? S[__builtin_amdgcn_readlane(co, u) + lane] : 0.0;
+  WAVE_SYNC();
+  double bs = bj;
+  double dA[8], zA[8], dB[8], zB[8];
+  uint32_t vb = 0u;
+  // (cp[h]: the chain value in front of half-block h -- the last wavefront has walked them all: quad_slow's starting points;
+  // the (dz, z_c) of half-block h + 1 are requested before half-block h is worked on)
+#define BL_QSTEP(H, dX, zX, dY, zY)                      \
+  if constexpr ((H) < HB1) {                             \
+    if constexpr ((H) + 1 < HB1) run_load<((H) + 1 < 8 ? (H) + 1 : 7)>(zw, dY, zY); \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    cp[(H)] = bs;                                        \
+    if constexpr ((H) < HB0) {                           \
+      run_chain<(H)>(cur, dX, bs);                       \
+    } else {                                             \
+      uint32_t acc_ = 0u;                                \
+      run_calc<(H)>(cur, dX, zX, bs, acc_);              \
+      vb |= (acc_ >> 31) << (H);                         \
+    }                                                    \
+  }
+  run_load<0>(zw, dA, zA);
+  BL_QSTEP(0, dA, zA, dB, zB) BL_QSTEP(1, dB, zB, dA, zA) BL_QSTEP(2, dA, zA, dB, zB) BL_QSTEP(3, dB, zB, dA, zA)
+  BL_QSTEP(4, dA, zA, dB, zB) BL_QSTEP(5, dB, zB, dA, zA) BL_QSTEP(6, dA, zA, dB, zB) BL_QSTEP(7, dB, zB, dA, zA)
+#undef BL_QSTEP
+  if (lastrow) vb = 0u;
+  bs_out = bs;
+  return wave_or_u32(vb);                                    // bit h: half-block h failed somewhere in the matrix
+}
+
 // One scan of the constrained sweeps for P <= 64 (Logit.hpp:380-398) on ONE wavefront -- lane = row, beta_j in a register; L,
 // z and the scan's records in LDS: k_beta_sweeps_run's speculative segment (the scan's P moves are one segment) with nothing
 // to exchange and nothing to fetch ahead.  Returns the number of moves redone with their exact bounds.
@@ -1820,6 +1904,36 @@ __device__ __forceinline__ int solo_scan(const double* S, int ld, int P, int lan
     BL_SLOW_LOOP(cur, true, BL_EXCH_SOLO, 1)
   }
   if (has && !((exm >> lane) & 1ull)) sz[cq] = sq;
+  (void)ncareful; (void)nrepass; (void)tExact; (void)tRepass; (void)x1; (void)xl;
+  return nslow;
+}
+
+// What is left of a scan of P = 64 moves whose cheap pass (quad_pass) found half-blocks that need a closer look (Fb0), on
+// the wavefront that holds every column of the scan and every chain value: solo_scan's second part.
+__device__ __forceinline__ int quad_slow(const double (&cur)[64], const double (&cp)[8], double bs_end, uint32_t Fb0, int lane,
+                                         int cvec, double svec, double z1v, const double* Rk, double* zw, double* zk, double* zz,
+                                         double& bj)
+{
+  const int mcnt = 64, wave = 0;
+  const bool lastrow = lane >= 63;
+  const int cq = cvec, g4 = (lane < 5 ? lane : 0) * 4;
+  const double sq = svec, z1q = z1v;
+  const double* RkSeg = Rk;
+  double* sz = zz;
+  uint32_t* x1 = nullptr;
+  double* xl = nullptr;
+  unsigned par = 0;
+  constexpr bool prof = false;
+  unsigned long long ncareful = 0, nrepass = 0;
+  long long tExact = 0, tRepass = 0;
+  int nslow = 0;
+  const int nbw = 8;
+  const uint32_t tailbit = 0u;
+  double bs = bs_end, cp1 = cp[1], cp2 = cp[2], cp3 = cp[3], cp4 = cp[4], cp5 = cp[5], cp6 = cp[6], cp7 = cp[7];
+  uint32_t Fb = Fb0;
+  unsigned long long exm = 0ull;
+  BL_SLOW_LOOP(cur, true, BL_EXCH_SOLO, 1)
+  if (!((exm >> lane) & 1ull)) sz[cq] = sq;
   (void)ncareful; (void)nrepass; (void)tExact; (void)tRepass; (void)x1; (void)xl;
   return nslow;
 }
@@ -2024,7 +2138,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_beta64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (mode == B_CONSTRAINED) hipLaunchKernelGGL(k_beta64_records, dim3((a.P * a.P + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode);
+    hipLaunchKernelGGL(k_beta64, dim3(1), dim3(kBlock), lds, s, a, mode, beta_row_split() ? 1 : 0);
     return;
   }
   // P > 64: factor (one workgroup) -> inverse (a workgroup per 64 columns) -> finish (one workgroup) [-> sweeps]

@@ -35,6 +35,25 @@ for P in (1, 2, 5, 8, 13, 24, 37, 60, 63, 64):
         h = np.ascontiguousarray(np.stack(hist))
         print(f"{tag:20s} P {P:3d} constrain {con} beta sha {hashlib.sha256(h.tobytes()).hexdigest()[:16]} last {h[-1, 0]:.17g}")
 
+# chains pressed against their bounds (few rows per coefficient: most moves need their bounds, the scans go move by move and
+# come back to speculating every eighth scan) and in between
+for N, P in ((2560, 64), (6400, 64), (20000, 64), (1500, 50)):
+    X, y, bt = bench.synth_logit(D, dev, N, P)
+    nn = torch.ones(N, dtype=torch.float64, device=dev)
+    sh = D.GibbsShard(X, y, nn, seed=5 + N)
+    sh.set_prior(np.zeros(P), np.eye(P) * 0.01)
+    sh.set_bp_local()
+    sh.finish_bp()
+    sh.set_beta(np.full(P, 0.02))
+    hist = []
+    for s in range(10):
+        sh.sweep_local(s, None)
+        sh.draw_beta(s, 1)
+        hist.append(sh.get_beta().copy())
+    D.sync_status()
+    h = np.ascontiguousarray(np.stack(hist))
+    print(f"{tag:20s} pressed N {N:6d} P {P:3d} beta sha {hashlib.sha256(h.tobytes()).hexdigest()[:16]} min beta {h[-1, :-1].min():.3e}")
+
 N, P = 2000000, 64
 X, y, bt = bench.synth_logit(D, dev, N, P)
 nn = torch.ones(N, dtype=torch.float64, device=dev)

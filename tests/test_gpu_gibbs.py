@@ -723,13 +723,15 @@ def test_call_sequence_streams_are_separate(gpu, oracle):
     assert np.allclose(out["beta"], bo, rtol=1e-8, atol=1e-9)
 
 
-@pytest.mark.parametrize("P", [65, 70, 127, 128, 129, 191, 193, 200, 255, 256])
+@pytest.mark.parametrize("P", [64, 65, 70, 127, 128, 129, 191, 193, 200, 255, 256])
 def test_constrained_sweeps_two_kernels_same_bits(gpu, P):
     """The coordinate sweeps of the constrained draw for 64 < P <= 256 (Logit.hpp:368-399) exist as two kernels -- rows
     split over four wavefronts in speculative segments of 64 moves (the default, which hands a chain that is pressed
     against its bounds to the other), all rows on one wavefront move by move: the same beta, bit for bit,
     on a posterior with slack constraints (data-rich: almost every move takes its first normal) and on one pressed
-    against them (most moves need their bounds; the default kernel's hand-over happens inside the six draws)."""
+    against them (most moves need their bounds; the default kernel's hand-over happens inside the six draws).
+    P = 64: the scans' cheap pass on four wavefronts (the default: 32 / 16 / 8 / 8 moves each, the chain walked again by
+    each up to its own moves) against the one-wavefront scans every P < 64 takes."""
     from bayeslogit_amd import device as D
     rng = np.random.default_rng(900 + P)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=gpu)
