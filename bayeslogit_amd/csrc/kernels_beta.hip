@@ -909,8 +909,10 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
   __shared__ int bad;
   __shared__ int progress;                           // wavefront 0's pivots done (kCholFailed: not positive definite)
   __shared__ __attribute__((aligned(16))) double s_piv2[64];  // the multipliers of wavefront 2's Cholesky
+  __shared__ int progress2;                          // wavefront 2's pivots of chol(S) done
   if (t == 0) bad = 0;
   if (t == 0) progress = 0;
+  if (t == 0) progress2 = 0;
   if (a.dbg && t == 0) a.dbg[0] = wall_clock64();
   for (int e = t; e < P * P; e += kBlock) {
     const int i = e % P, j = e / P;
@@ -962,7 +964,27 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
       double m = lane < P ? a.bP[lane] : 0.0;
       m = w_solve_Ut_vec(A, m, P, ld, lane);
       m = w_solve_U_vec(A, m, P, ld, lane);
-      if (lane < P) mP[lane] = m;
+      // z = L^{-1}(beta_prev - mP) (Logit.hpp:359-365), a step behind wavefront 2's pivots of chol(S) (step i needs column i
+      // of L), and beside it 1/L where L < 0 into A (U is dead: this wavefront and wavefront 2's inverse were its last
+      // readers) -- see the table of wavefront 1 below
+      double z = lane < P ? a.beta_prev[lane] - m : 0.0;
+      const double nan = __builtin_nan("");
+      bool live = true;
+      for (int i = 0; i < P && live; ++i) {
+        int done;
+        while ((done = __hip_atomic_load(&progress2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= i) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (done >= kCholFailed) {
+          live = false;
+          break;
+        }
+        const double l = (lane >= i && lane < P) ? L_(S, lane, i) : 0.0;
+        const double bi = bcast_f64(z, i) / bcast_f64(l, i);
+        if (lane == i) z = bi;
+        if (lane > i) z -= l * bi;                       // (l = 0 outside the matrix)
+        if (lane < P) L_(A, lane, i) = (l < 0.0 && lane < P - 1) ? 1.0 / l : nan;
+      }
+      if (live && lane < P) zz[lane] = z;
     }
   } else if (t >= 128 && t < 192) {
     const int lane = t - 128;
@@ -988,11 +1010,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
       } else {
         // B_CONSTRAINED set-up, Logit.hpp:335-366 (z: after the barrier, when mP is there)
         if (a.dbg && lane == 0) a.dbg[1] = wall_clock64();
-        ok = w_chol_rl<true>(S, P, ld, lane, s_piv2);                         // L = chol(S,'L')
+        ok = w_chol_rl<true>(S, P, ld, lane, s_piv2, &progress2);             // L = chol(S,'L')
         if (a.dbg && lane == 0) a.dbg[2] = wall_clock64();
       }
       if (!ok && lane == 0) bad = 1;
     }
+    // (a factorisation that failed: the wavefronts that follow this one's must not wait for pivots that will not come)
+    if (!ok && lane == 0) __hip_atomic_store(&progress2, kCholFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else if (mode == blk::B_CONSTRAINED && t >= 64 && t < 128) {
     // ====== wave 1, meanwhile: the scan tables.  (The tnorm records -- every other random input of the draw, in stream
     // order: DESIGN.md section 2 -- come from k_beta64_records, launched in front of this kernel: three wavefronts took 118 us
@@ -1022,6 +1046,18 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
       WAVE_SYNC();
     }
     if (a.dbg && t == 64) a.dbg[11] = wall_clock64();
+    // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0 (here), A where L < 0
+    // (wavefront 0), NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Column by column behind the pivots of
+    // chol(S), as wavefront 0's z.
+    const double nan = __builtin_nan("");
+    for (int i = 0; i < P; ++i) {
+      int done;
+      while ((done = __hip_atomic_load(&progress2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) <= i) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (done >= kCholFailed) break;
+      const double l = (tt >= i && tt < P) ? L_(S, tt, i) : 0.0;
+      if (tt < P) L_(Ri, tt, i) = (l > 0.0 && tt < P - 1) ? 1.0 / l : nan;
+    }
   }
   if (a.dbg && t == 0) a.dbg[5] = wall_clock64();
   __syncthreads();
@@ -1031,22 +1067,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
   }
   if (mode != blk::B_CONSTRAINED) return;
 
-  // 1/L split by the sign test of Logit.hpp:384-391 (see constrained_wide_prepare): Ri where L > 0, A (U is
-  // dead by now) where L < 0, NaN elsewhere -- v_max/v_min and the compare masks ignore NaN.  Waves 1-3; wave 0
-  // solves for z meanwhile.
-  for (int e = t - 64; e >= 0 && e < P * P; e += kBlock - 64) {
-    const int i = e % P, j = e / P;
-    const double l = L_(S, i, j), r = 1.0 / l;
-    const double nan = __builtin_nan("");
-    L_(Ri, i, j) = (l > 0.0 && i < P - 1) ? r : nan;
-    L_(A, i, j) = (l < 0.0 && i < P - 1) ? r : nan;
-  }
-  if (t < 64) {
-    double z = t < P ? a.beta_prev[t] - mP[t] : 0.0;                         // z = L^{-1}(beta_prev - mP)
-    z = w_solve_L_vec(S, z, P, ld, t);
-    if (t < P) zz[t] = z;
-  }
-  __syncthreads();                                 // 1/L complete
 
   if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
   if (a.dbg && t == 0) a.dbg[9] = clock64();

@@ -386,9 +386,7 @@ __global__ __launch_bounds__(1024) void k_reduce_fused(const double* __restrict_
   __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int s = threadIdx.x >> 6;            // 16 waves: wave s sums slabs s, s+16, ... (fixed order)
-  double sum = 0.0;
-  if (e < E)
-    for (int b = s; b < nparts; b += 16) sum += partial[(size_t)b * E + e];
+  const double sum = e < E ? blk::slab_sum16(partial, E, e, s, nparts) : 0.0;
   sm[s][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s == 0 && e < E) {
@@ -534,9 +532,7 @@ __global__ __launch_bounds__(1024) void k_reduce_big(const double* __restrict__ 
   __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int s = threadIdx.x >> 6;
-  double sum = 0.0;
-  if (e < E)
-    for (int b = s; b < nparts; b += 16) sum += partial[(size_t)b * E + e];
+  const double sum = e < E ? blk::slab_sum16(partial, E, e, s, nparts) : 0.0;
   sm[s][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s == 0 && e < E) {

@@ -398,20 +398,7 @@ __global__ __launch_bounds__(1024) void k_reduce_q4(const double* __restrict__ p
   __shared__ double sm[16][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int s = threadIdx.x >> 6;            // 16 waves: wave s sums slabs s, s+16, ... (fixed order)
-  double sum = 0.0;
-  if (e < E) {
-    // 32 slabs requested at a time, added in the order they were always added in (one dependent load after the other was
-    // 0.33 us a slab: 21 us for the 1024 slabs of a sweep, a twentieth of a sweep at N = 1.25e6)
-    int b = s;
-    for (; b + 16 * 31 < nparts; b += 16 * 32) {
-      double v[32];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) v[q] = partial[(size_t)(b + 16 * q) * E + e];
-#pragma unroll
-      for (int q = 0; q < 32; ++q) sum += v[q];
-    }
-    for (; b < nparts; b += 16) sum += partial[(size_t)b * E + e];
-  }
+  const double sum = e < E ? blk::slab_sum16(partial, E, e, s, nparts) : 0.0;
   sm[s][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s == 0 && e < E) {

@@ -204,9 +204,7 @@ __global__ __launch_bounds__(1024) void k_reduce_q4_big(const double* __restrict
   __shared__ double sm[16][64];
   const int el = blockIdx.x * 64 + (threadIdx.x & 63);
   const int s16 = threadIdx.x >> 6;
-  double sum = 0.0;
-  if (el < E)
-    for (int b = s16; b < nparts; b += 16) sum += partial[(size_t)b * E + el];
+  const double sum = el < E ? blk::slab_sum16(partial, E, el, s16, nparts) : 0.0;
   sm[s16][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s16 == 0 && el < E) {
@@ -401,9 +399,7 @@ __global__ __launch_bounds__(1024) void k_reduce_q4_blk16(const double* __restri
   __shared__ double sm[16][64];
   const int el = blockIdx.x * 64 + (threadIdx.x & 63);
   const int s16 = threadIdx.x >> 6;
-  double sum = 0.0;
-  if (el < E)
-    for (int b = s16; b < nparts; b += 16) sum += partial[(size_t)b * E + el];
+  const double sum = el < E ? blk::slab_sum16(partial, E, el, s16, nparts) : 0.0;
   sm[s16][threadIdx.x & 63] = sum;
   __syncthreads();
   if (s16 == 0 && el < E) {
