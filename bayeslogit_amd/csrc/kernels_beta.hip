@@ -1070,8 +1070,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
 
   if (a.dbg && t == 0) a.dbg[7] = wall_clock64();
   if (a.dbg && t == 0) a.dbg[9] = clock64();
-  // The coordinate sweeps: a move reads only LDS and registers (the next scan's random records travel from
-  // global scratch to LDS while a scan runs: loaded into registers at its start, stored at its end).
+  // The coordinate sweeps: a move reads only LDS and registers.
   //
   // Fast path.  A move's value is almost always the Box-Muller normal s of its first attempt: the bounds
   // contain 0, are wider than sqrt(2 pi), and s falls inside (tnorm_lanes' first branch, attempt 0).  That
@@ -1081,14 +1080,14 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
   // the usual case, pass the second or third whatever their finite side is).  Only a move that fails all
   // three pays the 64-lane max/min and tnorm_lanes (0.3 % of the moves on C4).  Same values either way.
   //
-  // One speculative segment per scan, on wavefront 0 (solo_scan): every move of the scan is assumed to take attempt 0's
-  // normal s, so dz = s - z_c is known for the whole scan up front; the chain beta_j + L_jc dz runs move by move in
-  // registers with the first of the three tests above in feasibility form beside it (three FMAs and an OR per move, sign
-  // bits per half-block of 8), a failing half-block goes through the three tests, a move that fails those is redone with
-  // its bounds and everything behind it is taken again.  The other wavefronts stage the next scan's records meanwhile and
-  // receive beta through LDS at the scan's end.  A chain pressed against its bounds gains nothing from that: its scans go
-  // move by move on every wavefront alike (same inputs, same arithmetic: the replicas of beta stay identical without an
-  // exchange).  Same values as the move-by-move loop either way.
+  // One speculative segment per scan: every move of the scan is assumed to take attempt 0's normal s, so dz = s - z_c is known
+  // for the whole scan up front; the chain beta_j + L_jc dz runs move by move in registers with the first of the three tests
+  // above in feasibility form beside it (three FMAs and an OR per move, sign bits per half-block of 8), a failing half-block
+  // goes through the three tests, a move that fails those is redone with its bounds and everything behind it is taken again.
+  // P = 64: the cheap pass on the four wavefronts (quad_pass), the rest on the one that walked the whole chain (quad_slow);
+  // P < 64: all of it on wavefront 0 (solo_scan), beta reaching the others through LDS at the scan's end.  A chain pressed
+  // against its bounds gains nothing from that: its scans go move by move on every wavefront alike (same inputs, same
+  // arithmetic: the replicas of beta stay identical without an exchange).  Same values as the move-by-move loop either way.
   // z lives in LDS (zz): within a scan every coordinate is visited once, so the z_c of all of a scan's
   // moves are gathered at its start (z1v) and the new values are scattered at its end.
   const int lane = t & 63, wave = t >> 6;
