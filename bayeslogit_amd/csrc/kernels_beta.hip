@@ -855,7 +855,7 @@ __device__ double w_solve_L_vec(const double* Lm, double b, int P, int ld, int l
 // the cheap pass of a scan of P = 64 moves on the four wavefronts, 16 moves each (defined with k_beta_sweeps_run's pieces, below)
 template <int HB0, int HB1>
 __device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane, int cvec, double svec, double z1v, double* zw,
-                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8]);
+                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8], const double* Rk);
 // ... and what is left of such a scan when some move needs its bounds, on the wavefront that walked the whole chain
 __device__ __forceinline__ int quad_slow(const double (&cur)[64], const double (&cp)[8], double bs_end, uint32_t Fb0, int lane,
                                          int cvec, double svec, double z1v, const double* Rk, double* zw, double* zk, double* zz,
@@ -1128,10 +1128,10 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
       switch (wave) {
         // (a wave pays 36 cycles for a move it only walks -- its column of L, its term of the chain -- and 77 for one it
         // tests: 32 / 16 / 8 / 8 moves even the four out)
-        case 0: vb = quad_pass<0, 4>(S, ld, lane, cvec, svec, z1v, s_zw[0], bj, bs, cur, cp); break;
-        case 1: vb = quad_pass<4, 6>(S, ld, lane, cvec, svec, z1v, s_zw[1], bj, bs, cur, cp); break;
-        case 2: vb = quad_pass<6, 7>(S, ld, lane, cvec, svec, z1v, s_zw[2], bj, bs, cur, cp); break;
-        default: vb = quad_pass<7, 8>(S, ld, lane, cvec, svec, z1v, s_zw[3], bj, bs, cur, cp); break;
+        case 0: vb = quad_pass<0, 4>(S, ld, lane, cvec, svec, z1v, s_zw[0], bj, bs, cur, cp, Rk); break;
+        case 1: vb = quad_pass<4, 6>(S, ld, lane, cvec, svec, z1v, s_zw[1], bj, bs, cur, cp, Rk); break;
+        case 2: vb = quad_pass<6, 7>(S, ld, lane, cvec, svec, z1v, s_zw[2], bj, bs, cur, cp, Rk); break;
+        default: vb = quad_pass<7, 8>(S, ld, lane, cvec, svec, z1v, s_zw[3], bj, bs, cur, cp, Rk); break;
       }
       if (lane == 0) s_fb[k & 1][wave] = vb;
       if (wave == 3) s_bj[k & 1][lane] = bs;
@@ -1849,7 +1849,7 @@ __device__ __forceinline__ void run_chain(const double (&l1)[64], const double (
 }
 template <int HB0, int HB1>      // the wave tests half-blocks HB0 .. HB1 - 1 (of eight moves each) and walks the chain up to them
 __device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane, int cvec, double svec, double z1v, double* zw,
-                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8])
+                                              double bj, double& bs_out, double (&cur)[64], double (&cp)[8], const double* Rk)
 {
   const bool lastrow = lane == 63;                           // row P-1 is not constrained (Logit.hpp:383: j < P-1)
   *reinterpret_cast<double2*>(zw + 2 * lane) = make_double2(svec - z1v, z1v);
@@ -1881,7 +1881,29 @@ __device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane,
 #undef BL_QSTEP
   if (lastrow) vb = 0u;
   bs_out = bs;
-  return wave_or_u32(vb);                                    // bit h: half-block h failed somewhere in the matrix
+  vb = wave_or_u32(vb);                                      // bit h: half-block h failed the cheap test somewhere in the matrix
+  // A half-block that fails the cheap test goes through the three sufficient tests here, on the wavefront that holds it (a
+  // coordinate that sits within 1.26 of its bound fails the cheap test in every scan of the draw and passes one of the
+  // one-sided ones: such a scan used to cost 2 600 cycles on the slow path, a draw of them 0.08 ms).  Only a half-block
+  // with a move that needs its bounds is reported.
+  for (uint32_t rem = vb; rem != 0u; rem &= rem - 1u) {
+    const int h = __builtin_ctz(rem);
+    double l8[8], bs0 = 0.0;
+#define BL_QHALF(H)                                                      \
+  if constexpr (HB0 <= (H) && (H) < HB1)                                  \
+    if (h == (H)) {                                                       \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) l8[u] = cur[8 * (H) + u]; \
+      bs0 = cp[(H)];                                                      \
+    }
+    BL_QHALF(0) BL_QHALF(1) BL_QHALF(2) BL_QHALF(3) BL_QHALF(4) BL_QHALF(5) BL_QHALF(6) BL_QHALF(7)
+#undef BL_QHALF
+    double bb;
+    ExactIn xin;
+    unsigned par = 0;
+    const uint32_t f = run_half<true>(l8, h, bs0, lastrow, lane, 0, 0, 64, zw, nullptr, par, Rk, (lane < 5 ? lane : 0) * 4, bb, xin);
+    if (f == 0u) vb &= ~(1u << h);
+  }
+  return vb;
 }
 
 // One scan of the constrained sweeps for P <= 64 (Logit.hpp:380-398) on ONE wavefront -- lane = row, beta_j in a register; L,
