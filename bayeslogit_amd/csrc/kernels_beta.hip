@@ -713,14 +713,12 @@ template <bool LOWER, bool MIRROR, int Q>
 __device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, double* M, int P, int ld, int lane, double* buf, int* progress)
 {
   const int k_end = P < 16 * Q + 16 ? P : 16 * Q + 16;
+  bool bad = false;
 #pragma nounroll
   for (int k = 16 * Q; k < k_end; ++k) {
     const double c = quarter_of<Q>(r0, r1, r2, r3)[k & 15];
     const double akk = bcast_f64(c, k);
-    if (!(akk > 0.0)) {
-      if (progress && lane == 0) __hip_atomic_store(progress, kCholFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      return false;
-    }
+    bad |= !(akk > 0.0);                             // looked at behind the quarter's last pivot: no branch on the pivot's path
     const double d = sqrt(akk);
     double u = 0.0;
     if (lane > k && lane < P) u = c / d;
@@ -735,6 +733,10 @@ __device__ __forceinline__ bool chol_phase(d16& r0, d16& r1, d16& r2, d16& r3, d
     if (progress && lane == 0) __hip_atomic_store(progress, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     axpy_quarters<Q, 3, true>(r0, r1, r2, r3, lds_addr(buf), u);
     WAVE_SYNC();
+  }
+  if (bad) {                                         // (NaNs since the pivot that was not positive: nothing reads them as results)
+    if (progress && lane == 0) __hip_atomic_store(progress, kCholFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return false;
   }
   return true;
 }
