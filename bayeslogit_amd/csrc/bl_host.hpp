@@ -22,7 +22,7 @@ int  collect_status(hipStream_t s);         // sync + read + reset flags
 // rpg_alt / rpg_sp (every h != 0 is a member; the kernel writes every element of x itself: no zeroing launch in front);
 // kHybFirst = the first class pass of rpg_hybrid: it also counts the members of every class into cls_count[6] and writes
 // the zeros of the b <= 0 branch; kHybLater = a later class pass: returns at once when cls_count says its class is empty.
-enum : int { kHybNone = 0, kHybFirst = 1, kHybLater = 2 };
+enum : int { kHybNone = 0, kHybFirst = 1, kHybLater = 2, kHybPlain = 3 };   // kHybPlain: a class pass that does not look at the counts
 int launch_rpg_tasks(bool sp, double* x, const double* h, const double* z, int64_t num, int* iter, uint64_t seed,
                      uint32_t epoch, uint64_t idx0, int hybrid, unsigned long long* cls_count, hipStream_t s);
 unsigned long long* class_counts_slot();    // 8 device counters for one rpg_hybrid call (a ring of 64 slots)

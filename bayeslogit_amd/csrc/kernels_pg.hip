@@ -380,6 +380,39 @@ int bl_rpg_hybrid_dev(double* x, const double* h, const double* z, int64_t num, 
   // zeroing launch over x: every element is written by exactly one pass.
   unsigned long long* cc = blh::class_counts_slot();
   BL_HIP_TRY(hipMemsetAsync(cc, 0, 8 * sizeof(unsigned long long), s));
+  // The class passes write disjoint elements of x and read h and z only: the alternating-series kernel and the Devroye pass
+  // go to two streams of their own beside the saddle-point kernel (all three scan every shape themselves), so that the
+  // workgroups of one fill the CUs the last workgroups of another leave idle; the two classes that are usually empty wait
+  // for the first pass's counts on the caller's stream.  BL_HYBRID_STREAMS=0: one stream, one pass after the other.
+  static const bool fan = !(getenv("BL_HYBRID_STREAMS") && atoi(getenv("BL_HYBRID_STREAMS")) == 0);
+  static hipStream_t s1 = nullptr, s2 = nullptr;
+  static hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  static bool made = false, usable = false;
+  if (fan && !made) {
+    made = true;
+    usable = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) == hipSuccess &&
+             hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+  }
+  if (fan && usable) {
+    BL_HIP_TRY(hipEventRecord(e0, s));                       // x, h, z are the caller's as of here
+    BL_HIP_TRY(hipStreamWaitEvent(s1, e0, 0));
+    BL_HIP_TRY(hipStreamWaitEvent(s2, e0, 0));
+    if (int rc = blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybFirst, cc, s)) return rc;     // saddle point
+    if (int rc = blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybPlain, nullptr, s1)) return rc;   // alternating series
+    hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s2, x, h, z, num, seed, epoch, idx0,
+                       (const unsigned long long*)nullptr, blh::status_word(s));
+    BL_HIP_TRY(hipEventRecord(e1, s1));
+    BL_HIP_TRY(hipEventRecord(e2, s2));
+    hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_NORMAL>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
+    hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_GAMMA>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
+    BL_HIP_TRY(hipStreamWaitEvent(s, e1, 0));
+    BL_HIP_TRY(hipStreamWaitEvent(s, e2, 0));
+    BL_HIP_TRY(hipGetLastError());
+    return BL_OK;
+  }
   if (int rc = blh::launch_rpg_tasks(true, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybFirst, cc, s)) return rc;    // saddle point
   if (int rc = blh::launch_rpg_tasks(false, x, h, z, num, nullptr, seed, epoch, idx0, blh::kHybLater, cc, s)) return rc;   // alternating series
   hipLaunchKernelGGL(k_rpg_hybrid_class<bl::CLS_DEVROYE>, g, b, 0, s, x, h, z, num, seed, epoch, idx0, cc, st);
