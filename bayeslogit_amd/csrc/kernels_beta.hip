@@ -2186,13 +2186,28 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   }
   // P > 64: factor (one workgroup) -> inverse (a workgroup per 64 columns) -> finish (one workgroup) [-> sweeps]
   const bool wide = mode == B_CONSTRAINED && a.P <= 256;
-  if (wide) hipLaunchKernelGGL(k_beta_records, dim3(64), dim3(256), 0, s, a);
+  // The draw's random inputs (records, scan tables: 0.16 ms at P = 256) depend on (seed, epoch, P) alone and the dense stage
+  // (1.4 ms of one-workgroup kernels) on X'Omega X alone: the inputs go to a stream of the library's own beside it, behind
+  // everything the caller's stream holds so far (the last draw's sweeps read the same workspace); the sweeps wait for both.
+  static hipStream_t side = nullptr;
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  static bool made = false, usable = false;
+  if (wide && !made) {
+    made = true;
+    usable = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess;
+  }
+  const bool fan = wide && usable && hipEventRecord(e0, s) == hipSuccess && hipStreamWaitEvent(side, e0, 0) == hipSuccess;
+  hipStream_t si = fan ? side : s;
+  if (wide) hipLaunchKernelGGL(k_beta_records, dim3(64), dim3(256), 0, si, a);
   if (wide && beta_row_split()) {
     const size_t lt = 2 * (size_t)a.P * a.P;
     if (lt > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)k_beta_scan_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lt);
-    hipLaunchKernelGGL(k_beta_scan_tables, dim3(1), dim3(1024), lt, s, a);
+    hipLaunchKernelGGL(k_beta_scan_tables, dim3(1), dim3(1024), lt, si, a);
   }
+  if (fan) (void)hipEventRecord(e1, side);
   hipLaunchKernelGGL(k_beta_factor, dim3(1), dim3(kDenseThreads), 0, s, a, mode);
   if (mode == B_SOLVE || mode == B_MVN) return;
   {
@@ -2205,6 +2220,7 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
     (void)hipFuncSetAttribute((const void*)k_beta_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_beta_finish, dim3(1), dim3(kDenseThreads), lds, s, a, mode);
+  if (fan) (void)hipStreamWaitEvent(s, e1, 0);
   if (wide) lds = (2 * (size_t)a.P * kRec + (size_t)a.P) * 8 + (size_t)a.P * a.P + 64;   // the one-wavefront sweeps' LDS
   if (wide && beta_row_split()) {
     const size_t l2 = ((((size_t)a.P + 1) & ~(size_t)1) + 16 + 16 + 4 + 512 + 256) * 8;
