@@ -226,18 +226,19 @@ int bl_gibbs_draw_beta(bl_gibbs* h, uint32_t sweep, int constrain)
     unsigned long long st[32];
     (void)hipMemcpyAsync(st, dbuf, sizeof(st), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
-    fprintf(stderr, "beta stage (us): chol %.1f inverse %.1f rest of dense (wave 0; waves 1-3 generate randoms) %.1f scan tables %.1f serial %.1f\n",
-            (st[3] - st[0]) / 100.0, st[4] ? (st[4] - st[3]) / 100.0 : 0.0, (st[5] - (st[4] ? st[4] : st[3])) / 100.0,
-            st[7] ? (st[7] - st[5]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
+    // P <= 64, constrained: stamps of wavefront 0 (chol(PP) done: st[3]), of wavefront 2 (inverse done: st[4]; chol(S) from
+    // st[1] to st[2]) and of the workgroup (dense stage over, sweeps start: st[7]; end: st[6])
+    fprintf(stderr, "beta stage (us): chol(PP) %.1f, inverse done %.1f later, chol(S) %.1f, dense stage over at %.1f, sweeps %.1f\n",
+            (st[3] - st[0]) / 100.0, st[4] ? (st[4] - st[3]) / 100.0 : 0.0, st[2] ? (st[2] - st[1]) / 100.0 : 0.0,
+            st[7] ? (st[7] - st[0]) / 100.0 : 0.0, st[7] ? (st[6] - st[7]) / 100.0 : 0.0);
     if (st[7]) fprintf(stderr, "  moves redone move by move: %llu; shader clock over the sweeps: %.0f MHz\n", st[8],
                        (double)(st[10] - st[9]) / ((st[6] - st[7]) / 100.0));
     if (st[12]) fprintf(stderr, "  row-split sweeps: %llu moves with exact bounds, %llu groups (blocks through the three tests), %llu segments taken again behind an exact move\n", st[8], st[12], st[13]);
     if (st[19]) fprintf(stderr, "  shader cycles: sweeps %llu = segment set-up %llu + blocks that passed %llu + blocks with an exact move %llu + rest\n",
                         st[19], st[16], st[17], st[18]);
     if (st[19]) fprintf(stderr, "  cheap test: LDS hand-over %llu arithmetic %llu verdict exchange %llu  (segments of 64: exact moves %llu, passes taken again %llu)\n", st[20], st[21], st[22], st[20], st[21]);
-    if (st[11]) fprintf(stderr, "  random inputs generated (waves 1-3) after %.1f us\n", (st[11] - st[0]) / 100.0);
+    if (st[11]) fprintf(stderr, "  scan tables (wavefront 1) ready after %.1f us\n", (st[11] - st[0]) / 100.0);
     if (st[14]) fprintf(stderr, "  scans as one segment on wavefront 0: %llu shader cycles inside them\n", st[14]);
-    if (st[1]) fprintf(stderr, "  rest: mP solves %.1f chol_lower %.1f after %.1f\n", (st[1] - st[4]) / 100.0, (st[2] - st[1]) / 100.0, (st[5] - st[2]) / 100.0);
   }
   return BL_OK;
 }

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
       }
     } else
     if (spec_on) {
-      // the scan as one speculative segment on wavefront 0 (the others stage the next records and wait)
+      // the scan as one speculative segment on wavefront 0 (the others wait)
       if (wave == 0) {
         const long long tq0 = a.dbg ? clock64() : 0;
         nfail = solo_scan(S, ld, P, lane, cvec, svec, z1v, Rk, s_zw[0], s_zk, zz, bj);
