@@ -1108,10 +1108,13 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
   // into LDS first.
   bool spec_on = true;
   double svec_n = row ? rec[lane * kRec + 3] : 0.0;                 // lane i: attempt 0's normal of move i of scan 0
+  int cvec_n = row ? ptab[lane] : 0;                                 //         coordinate of move i of scan 0
   for (int k = 0; k < P; ++k) {
     const double* Rk = rec + (size_t)k * nrec;
     const double svec = svec_n;
+    const int cvec = cvec_n;                                         // (both a scan ahead: the scan's first LDS read is z's)
     if (k + 1 < P) svec_n = row ? rec[(size_t)(k + 1) * nrec + lane * kRec + 3] : 0.0;
+    if (k + 1 < P) cvec_n = row ? ptab[(k + 1) * P + lane] : 0;
     if (!spec_on) {
       for (int e = t; e < nrec; e += kBlock) recL[e] = Rk[e];
       __syncthreads();
@@ -1119,7 +1122,6 @@ __global__ __launch_bounds__(kBlock) void k_beta64(blk::BetaArgs a, int mode, in
     }
     const int g4 = (lane < 5 ? lane : 0) * 4;
     const double qnan = __builtin_nan("");
-    const int cvec = row ? ptab[k * P + lane] : 0;               // lane i: coordinate of move i
     const double z1v = row ? zz[cvec] : 0.0;                     // lane i: z_c before move i
     int nfail = 0;                                                 // moves taken with their exact bounds in this scan
     if (spec_on && quad) {
