@@ -7,6 +7,7 @@
 // SGPRs through v_writelane in the move loops.
 #include "bl_gibbs_kernels.hpp"
 #include "bl_host.hpp"
+#include <mutex>
 #include "bl_pg_devroye.hpp"
 #include "bl_pg1_queue.hpp"
 #include "../../include/bayeslogit_hip.h"
@@ -2191,6 +2192,9 @@ void launch_beta(const BetaArgs& a, int mode, hipStream_t s)
   // The draw's random inputs (records, scan tables: 0.16 ms at P = 256) depend on (seed, epoch, P) alone and the dense stage
   // (1.4 ms of one-workgroup kernels) on X'Omega X alone: the inputs go to a stream of the library's own beside it, behind
   // everything the caller's stream holds so far (the last draw's sweeps read the same workspace); the sweeps wait for both.
+  static std::mutex mu;               // the side stream and its events are the library's: one call's record / wait pairs at a time
+  std::unique_lock<std::mutex> lock(mu, std::defer_lock);
+  if (wide) lock.lock();
   static hipStream_t side = nullptr;
   static hipEvent_t e0 = nullptr, e1 = nullptr;
   static bool made = false, usable = false;

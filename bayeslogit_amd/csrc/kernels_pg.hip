@@ -2,6 +2,7 @@
 // each observation on its own Philox stream.  Replaces the serial loops of
 // Code/C/LogitWrapper.cpp:39-167.  gfx950 only.
 #include "bl_host.hpp"
+#include <mutex>
 #include "bl_pg_hybrid.hpp"
 #include "bl_pg1_queue.hpp"
 
@@ -385,6 +386,8 @@ int bl_rpg_hybrid_dev(double* x, const double* h, const double* z, int64_t num, 
   // workgroups of one fill the CUs the last workgroups of another leave idle; the two classes that are usually empty wait
   // for the first pass's counts on the caller's stream.  BL_HYBRID_STREAMS=0: one stream, one pass after the other.
   static const bool fan = !(getenv("BL_HYBRID_STREAMS") && atoi(getenv("BL_HYBRID_STREAMS")) == 0);
+  static std::mutex mu;               // the side streams and events are the library's: one call's record / wait pairs at a time
+  std::lock_guard<std::mutex> lock(mu);
   static hipStream_t s1 = nullptr, s2 = nullptr;
   static hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   static bool made = false, usable = false;
