@@ -346,19 +346,23 @@ BL_HD bool pg1_attempt(Pg1Lane& s, const Pg1Par& p, double u1, double u2, int& s
 // build) on the observation's own stream, as a per-lane loop over Philox blocks.  Lanes of a
 // wave run it in lockstep; a lane that finishes early idles until its wave does (the work queue
 // of bl_pg1_queue.hpp avoids that wait).
-BL_HD double pg1_draw_n(int n, double z, uint64_t seed, uint64_t idx, uint32_t domain, uint32_t epoch, int& status)
+// blk0 > 0 (n == 1 only): the observation's blocks 0 .. blk0 - 1 are known to have been retries inside the left piece (the
+// single-pass sweep's ahead-of-time attempts): the draw goes on at block blk0 as the retry it is -- an attempt is a function
+// of its block and of `fresh` alone.
+BL_HD double pg1_draw_n(int n, double z, uint64_t seed, uint64_t idx, uint32_t domain, uint32_t epoch, int& status,
+                        uint32_t blk0 = 0)
 {
   if (n < 1) {
     n = 1;
     status |= 2;
   }
   const Pg1Par p = pg1_par(z);
-  Pg1Lane s{true, 0.0};
+  Pg1Lane s{blk0 == 0, 0.0};
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const uint32_t c0 = (uint32_t)idx, c1 = ctr1_of(idx, domain);
   double sum = 0.0;
   uint32_t cap = kPg1BlkCap;         // first block the current draw may not use
-  for (uint32_t blk = 0; blk != cap; ++blk) {
+  for (uint32_t blk = blk0; blk != cap; ++blk) {
     const U4 o = philox4x32_10(c0, c1, epoch, blk, k0, k1);
     if (pg1_attempt(s, p, u52(o.x, o.y), u52(o.z, o.w), status)) {
       sum += 0.25 * s.X;

@@ -80,14 +80,14 @@ constexpr int kSubStart[5] = {0, 10, 20, 30, 36};     // instructions of rotatio
 
 // the full sampler for a deferred row (any class, any n): the observation's stream from block 0
 __device__ __attribute__((noinline)) double draw_full(int n, double psi, uint64_t seed, uint64_t idx, uint32_t epoch,
-                                                      int* status)
+                                                      int* status, uint32_t blk0)
 {
   // arguments of an out-of-line function arrive in VGPRs; the key is wave-uniform and goes back to SGPRs
   const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seed);
   const uint32_t s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seed >> 32));
   epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch);
   int st = 0;
-  const double om = pg1_draw_n(n, psi, ((uint64_t)s1 << 32) | s0, idx, DOM_OMEGA, epoch, st);   // Logit.hpp:287
+  const double om = pg1_draw_n(n, psi, ((uint64_t)s1 << 32) | s0, idx, DOM_OMEGA, epoch, st, blk0);   // Logit.hpp:287
   if (st) atomicOr(status, st);
   return om;
 }
@@ -280,7 +280,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_once64(const double* __rest
     const uint64_t dm = __ballot(defer);
     if (defer) {
       const int64_t slot = r0 + nDef + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));   // the wave's list lives in its own row range
-      defRow[slot] = (uint32_t)(row - r0);
+      // bit 31: a fast row none of whose four attempts stopped -- four retries inside the left piece: the deferred kernel goes
+      // on at block 4 instead of taking the four again
+      defRow[slot] = (uint32_t)(row - r0) | ((fast && nStop == 0u) ? 0x80000000u : 0u);
       defPsi[slot] = psi;
     }
     nDef += __popcll(dm);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int row = 2 * p + (lane >> 5);
-      const int64_t grow = r0 + (int64_t)defRow[r0 + b + (row < c16 ? row : 0)];
+      const int64_t grow = r0 + (int64_t)(defRow[r0 + b + (row < c16 ? row : 0)] & 0x7FFFFFFFu);
       const double* src = tX + (size_t)grow * 64 + 16 * (((lane >> 3) & 3) ^ (row & 1)) + 2 * (lane & 7);
       __builtin_amdgcn_global_load_lds(src, &sTile[wave][s][1024 * p], 16, 0, 0);
     }
@@ -362,8 +364,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_sweep_deferred64(const double* __
     gather(b0, 0);                                          // on its way while the draws run
     double om = 0.0;
     if (lane < c64) {
-      const int64_t grow = r0 + (int64_t)defRow[r0 + b0 + lane];
-      om = draw_full((int)nvec[grow] /* (int) n(i), Logit.hpp:287 */, defPsi[r0 + b0 + lane], seed, idx0 + (uint64_t)grow, epoch, status);
+      const uint32_t dr = defRow[r0 + b0 + lane];
+      const int64_t grow = r0 + (int64_t)(dr & 0x7FFFFFFFu);
+      om = draw_full((int)nvec[grow] /* (int) n(i), Logit.hpp:287 */, defPsi[r0 + b0 + lane], seed, idx0 + (uint64_t)grow, epoch, status,
+                     (dr >> 31) ? 4u : 0u);
       if (w) w[grow] = om;
     }
     sOm[wave][lane] = om;                                   // 0 past the end of the list
