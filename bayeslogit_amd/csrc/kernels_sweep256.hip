@@ -79,13 +79,13 @@ __host__ __device__ constexpr int diag_idx(int mi, int ni, int r)
 
 // the full sampler for a deferred row (any class, any n): the observation's stream from block 0
 __device__ __attribute__((noinline)) double draw_full256(int n, double psi, uint64_t seed, uint64_t idx, uint32_t epoch,
-                                                         int* status)
+                                                         int* status, uint32_t blk0)
 {
   const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seed);
   const uint32_t s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(seed >> 32));
   epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)epoch);
   int st = 0;
-  const double om = pg1_draw_n(n, psi, ((uint64_t)s1 << 32) | s0, idx, DOM_OMEGA, epoch, st);   // Logit.hpp:287
+  const double om = pg1_draw_n(n, psi, ((uint64_t)s1 << 32) | s0, idx, DOM_OMEGA, epoch, st, blk0);   // Logit.hpp:287
   if (st) atomicOr(status, st);
   return om;
 }
@@ -229,7 +229,8 @@ __device__ __forceinline__ void wave_main(const Ctx& cx, const int wave, const i
     if (defer) {
       const int64_t slot = 16 * cx.t0 + nDef +
                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-      cx.defRow[slot] = (uint32_t)(row - 16 * cx.t0);
+      // bit 31: four retries inside the left piece -- the deferred kernel goes on at block 4 (kernels_sweep1.hip: settle)
+      cx.defRow[slot] = (uint32_t)(row - 16 * cx.t0) | ((fast && nStop == 0u) ? 0x80000000u : 0u);
       cx.defPsi[slot] = psi;
     }
     nDef += __popcll(dm);
@@ -412,13 +413,13 @@ __global__ __launch_bounds__(512, 2) void k_sweep_deferred256(const double* __re
       uint32_t ro = defRow[lbase + s0];        // past the end: the segment's first row, weight 0
       if (i < n) {
         ro = defRow[lbase + s0 + i];
-        const int64_t grow = lbase + (int64_t)ro;
+        const int64_t grow = lbase + (int64_t)(ro & 0x7FFFFFFFu);
         om = draw_full256((int)nvec[grow] /* (int) n(i), Logit.hpp:287 */, defPsi[lbase + s0 + i], seed, idx0 + (uint64_t)grow,
-                          epoch, status);
+                          epoch, status, (ro >> 31) ? 4u : 0u);
         if (w) w[grow] = om;
       }
       sOm[i] = om;
-      sRow[i] = ro;
+      sRow[i] = ro & 0x7FFFFFFFu;
     }
     __syncthreads();
     cx.ntl = (n + kRT - 1) / kRT;
