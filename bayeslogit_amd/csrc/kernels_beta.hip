@@ -1846,6 +1846,12 @@ __global__ __launch_bounds__(1024) void k_beta_scan_tables(blk::BetaArgs a)
 // and tests its own moves -- solo_scan's pass, element for element.  Returns the wave's verdict (bit h: half-block h
 // failed somewhere in the matrix) and in bs_out the chain value behind its last move (the last wavefront's is the scan's end).
 // zw: the wave's own 128-double slot.
+template <int H>      // the dz alone of half-block H (a wave that only walks the chain through it needs no z_c)
+__device__ __forceinline__ void run_load_dz(const double* zw, double (&dz)[8])
+{
+#pragma unroll
+  for (int u = 0; u < 8; ++u) dz[u] = zw[2 * (8 * H + u)];
+}
 template <int H>
 __device__ __forceinline__ void run_chain(const double (&l1)[64], const double (&dz)[8], double& bs)
 {
@@ -1869,7 +1875,8 @@ __device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane,
   // the (dz, z_c) of half-block h + 1 are requested before half-block h is worked on)
 #define BL_QSTEP(H, dX, zX, dY, zY)                      \
   if constexpr ((H) < HB1) {                             \
-    if constexpr ((H) + 1 < HB1) run_load<((H) + 1 < 8 ? (H) + 1 : 7)>(zw, dY, zY); \
+    if constexpr ((H) + 1 < HB0) run_load_dz<((H) + 1 < 8 ? (H) + 1 : 7)>(zw, dY);  \
+    else if constexpr ((H) + 1 < HB1) run_load<((H) + 1 < 8 ? (H) + 1 : 7)>(zw, dY, zY); \
     __builtin_amdgcn_sched_barrier(0);                   \
     cp[(H)] = bs;                                        \
     if constexpr ((H) < HB0) {                           \
@@ -1880,7 +1887,8 @@ __device__ __forceinline__ uint32_t quad_pass(const double* S, int ld, int lane,
       vb |= (acc_ >> 31) << (H);                         \
     }                                                    \
   }
-  run_load<0>(zw, dA, zA);
+  if constexpr (HB0 > 0) run_load_dz<0>(zw, dA);
+  else run_load<0>(zw, dA, zA);
   BL_QSTEP(0, dA, zA, dB, zB) BL_QSTEP(1, dB, zB, dA, zA) BL_QSTEP(2, dA, zA, dB, zB) BL_QSTEP(3, dB, zB, dA, zA)
   BL_QSTEP(4, dA, zA, dB, zB) BL_QSTEP(5, dB, zB, dA, zA) BL_QSTEP(6, dA, zA, dB, zB) BL_QSTEP(7, dB, zB, dA, zA)
 #undef BL_QSTEP
